@@ -1,0 +1,101 @@
+/*
+ * C ABI of libocean_hip.so - the gfx950 (MI355X) kernels behind the OCEAN
+ * per-step model hot path.
+ *
+ * The reference has no FFI layer: its boundary is the Python class API
+ * (ocean/models/__init__.py:3-15).  The Python package in this repository
+ * keeps those classes and binds these entry points with ctypes; each entry
+ * point cites the reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to contiguous fp32 unless stated;
+ *  - nothing here allocates, frees or synchronises: the caller owns every
+ *    buffer (outputs and workspaces included) and the work is enqueued on
+ *    `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *  - return value: 0 on success, else an OceanStatus code (1 bad shape,
+ *    2 unsupported size, 3 workspace too small, 4 null pointer,
+ *    1000 + hipError_t for a launch failure);
+ *  - gradient outputs named d<param> are ACCUMULATED into (+=); activation
+ *    gradients are overwritten unless stated.
+ */
+#ifndef OCEAN_HIP_H
+#define OCEAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCEAN_MAX_CONV_LAYERS 8
+
+/* Library/ABI version: bumped when a signature changes. */
+int ocean_abi_version(void);
+
+/* ------------------------------------------------------------------ GEMM
+ * C[M,N] = A . B (+bias)(+R)(ReLU).  fp32 in, fp32 accumulate on the matrix
+ * cores.  a_kmajor: A stored [K][M] instead of [M][K]; b_kn: B stored [K][N]
+ * instead of [N][K].  With a_kmajor the result is atomically ADDED to C.
+ * Replaces torch.nn.functional.linear / torch.mm wherever the reference calls
+ * them on the model path (e.g. multi_factor_attention.py:332-334). */
+int ocean_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   int M, int N, int K, int a_kmajor, int b_kn,
+                   const float* bias, const float* R, int ldr, int relu, void* stream);
+
+/* ------------------------------------------------------------------ DilatedCNN
+ * Replaces DilatedCNN.forward / DilatedConvBlock.forward
+ * (ocean/models/components/dilated_cnn.py:76-99, 195-241) and their autograd
+ * backward.  Activations are channels-last [B*T, C]; every Conv1d is an
+ * implicit GEMM with symmetric zero padding (k-1)*d/2 (dilated_cnn.py:45).
+ */
+typedef struct {
+  int B, T, F;                               /* input metrics [B,T,F]                      */
+  int L;                                     /* number of dilated blocks (1..8)            */
+  int channels[OCEAN_MAX_CONV_LAYERS];       /* block widths                               */
+  int dilations[OCEAN_MAX_CONV_LAYERS];
+  int kernel_size;                           /* odd                                        */
+  int out_dim;                               /* output_projection width                    */
+  int training;                              /* 1: batch statistics + running-stat update  */
+  float eps, momentum;                       /* BatchNorm1d: 1e-5, 0.1                     */
+  long bn_count;                             /* rows behind the BN statistics; B*T, or the
+                                                global row count when ranks all-reduce them */
+  float dropout;                             /* p of every nn.Dropout (dilated_cnn.py:58,175);
+                                                applied only when training                  */
+  uint64_t seed;                             /* dropout mask seed of this forward/backward   */
+} ocean_dcnn_shape;
+
+/* Parameter table order (pointers to device fp32):
+ *   [0] input_projection.weight [C0,F]  [1] input_projection.bias [C0]
+ *   then for block i in 0..L-1:   conv.weight [Ci,Ci,k], bn.weight, bn.bias, bn.running_mean, bn.running_var
+ *   then for transition i in 0..L-2: conv.weight [Ci+1,Ci,1], bn.weight, bn.bias, bn.running_mean, bn.running_var
+ *   then output_projection.weight [out,C_last], output_projection.bias [out].
+ * The gradient table has the same order; running_mean/var slots are ignored. */
+size_t ocean_dcnn_param_count(const ocean_dcnn_shape* s);
+
+/* Workspace sizes in floats.  The forward region must stay untouched between
+ * ocean_dcnn_fwd and ocean_dcnn_bwd (it holds the saved activations). */
+size_t ocean_dcnn_fwd_workspace(const ocean_dcnn_shape* s);
+size_t ocean_dcnn_bwd_workspace(const ocean_dcnn_shape* s);
+
+/* Number of phases of the forward / backward drivers.  A phase boundary is a
+ * point where BatchNorm column statistics are complete on this rank; a
+ * data-parallel caller all-reduces them there.  phase range [lo,hi). */
+int ocean_dcnn_num_phases(const ocean_dcnn_shape* s);
+/* Offset (in floats, into the fwd / bwd workspace) and length (in doubles) of
+ * the statistics block [2][C] (fp64) that is complete after phase `phase`. */
+int ocean_dcnn_stats_block(const ocean_dcnn_shape* s, int phase, int backward,
+                           size_t* offset_floats, int* n_doubles);
+
+int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* params,
+                   float* ws, size_t ws_floats, float* out /* [B,out_dim] */,
+                   int phase_lo, int phase_hi, void* stream);
+int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* params,
+                   float* ws_fwd, float* ws_bwd, size_t ws_bwd_floats,
+                   const float* dout /* [B,out_dim] */, float* const* grads,
+                   float* dx /* [B,T,F] or NULL */, int phase_lo, int phase_hi, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCEAN_HIP_H */

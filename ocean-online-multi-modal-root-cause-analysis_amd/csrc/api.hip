@@ -1,0 +1,19 @@
+// Generic entry points of the C ABI (see include/ocean_hip.h).
+#include "../../include/ocean_hip.h"
+#include "ops.h"
+
+extern "C" {
+
+int ocean_abi_version(void) { return 1; }
+
+int ocean_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                   int a_kmajor, int b_kn, const float* bias, const float* R, int ldr, int relu, void* stream) {
+  GemmP p = gemm_defaults();
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.a_kmajor = a_kmajor; p.b_kn = b_kn;
+  p.bias = bias; p.R = R; p.ldr = ldr; p.relu = relu;
+  p.split_k = a_kmajor ? 0 : 1;
+  return ocean_launch_gemm(p, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// Shared declarations for the OCEAN gfx950 kernel library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+// Status codes returned through the C ABI (0 = success).
+enum OceanStatus {
+  OCEAN_OK = 0,
+  OCEAN_ERR_BAD_SHAPE = 1,      // a dimension is <= 0 or inconsistent
+  OCEAN_ERR_UNSUPPORTED = 2,    // a size beyond a kernel's compiled limit
+  OCEAN_ERR_WORKSPACE = 3,      // caller workspace too small
+  OCEAN_ERR_NULL = 4,           // required pointer is null
+  OCEAN_ERR_HIP = 1000          // + hipError_t
+};
+
+#define OCEAN_LAUNCH_CHECK()                                  \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return OCEAN_ERR_HIP + (int)e__;   \
+  } while (0)
+
+#define OCEAN_TRY(x)                \
+  do {                              \
+    int s__ = (x);                  \
+    if (s__ != OCEAN_OK) return s__; \
+  } while (0)
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- dropout
+// Counter-based dropout: element `idx` of a site is kept iff hash(seed, idx) >= p,
+// so forward and backward regenerate the same mask without storing it.
+struct DropoutP { float p; uint64_t seed; };
+
+__host__ __device__ inline uint32_t ocean_hash32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+// multiplier applied to a surviving / dropped activation: 1/(1-p) or 0
+__host__ __device__ inline float dropout_keep(const DropoutP& d, uint64_t idx) {
+  const float u = (float)(ocean_hash32(d.seed, idx) >> 8) * (1.0f / 16777216.0f);   // [0,1)
+  return u >= d.p ? 1.0f / (1.0f - d.p) : 0.0f;
+}
+
+// ---------------------------------------------------------------- GEMM
+// C[M,N] (+)= sum over taps t, sum_k  A_t[m,k] * B_t[k,n]     fp32 MFMA (32x32x2).
+//
+// Operand storage:
+//   a_kmajor == 0 : A stored [m][k] (k contiguous, leading dim lda)
+//   a_kmajor == 1 : A stored [k][m] (m contiguous)
+//   b_kn     == 0 : B stored [n][k] (k contiguous, e.g. nn.Linear weight [out,in])
+//   b_kn     == 1 : B stored [k][n] (n contiguous)
+//
+// Row shifting (dilated-convolution taps over a [B*T, C] channels-last matrix):
+//   rows of the *M-like* index are (sample, time) pairs with time = row % T.
+//   For tap t the shift is s = shift0 + t*shift_step; a shifted row is read
+//   from row + s when 0 <= time + s < T and is zero otherwise.
+//   - a_kmajor == 0: the shift applies to A's rows (m); B advances by
+//     tap_stride_b per tap; all taps accumulate into one C.
+//   - a_kmajor == 1 (reduction over rows): the shift applies to B's rows (k);
+//     each tap writes its own C + t*tap_stride_c (grid.z covers taps*split_k).
+struct GemmP {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int a_kmajor, b_kn;
+  int taps, T, shift0, shift_step;
+  long tap_stride_b, tap_stride_c;
+  int split_k;              // only with a_kmajor == 1; C is then accumulated with atomics (must be pre-zeroed or hold the running sum)
+  const float* bias;        // [N] added to every row, or null
+  const float* R; int ldr;  // residual added elementwise, or null (R == C allowed: in-place accumulate)
+  int r_bcast_T; float r_scale;  // r_bcast_T > 0: residual row is R[row / r_bcast_T] (one row per sample), times r_scale
+  int relu;
+  double* colstats;         // [2][N] running (sum, sum of squares) of the pre-epilogue value, atomically accumulated, or null
+};
+
+int ocean_launch_gemm(const GemmP& p, hipStream_t stream);
+
+static inline GemmP gemm_defaults() {
+  GemmP p;
+  p.A = p.B = nullptr; p.C = nullptr; p.M = p.N = p.K = 0; p.lda = p.ldb = p.ldc = 0;
+  p.a_kmajor = 0; p.b_kn = 0; p.taps = 1; p.T = 0; p.shift0 = 0; p.shift_step = 0;
+  p.tap_stride_b = 0; p.tap_stride_c = 0; p.split_k = 1; p.bias = nullptr; p.R = nullptr; p.ldr = 0; p.r_bcast_T = 0; p.r_scale = 1.f;
+  p.relu = 0; p.colstats = nullptr;
+  return p;
+}

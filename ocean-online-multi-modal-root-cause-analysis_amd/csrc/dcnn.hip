@@ -1,0 +1,497 @@
+// DilatedCNN forward / backward driver and its BatchNorm / pooling kernels.
+//
+// Data layout: activations are channels-last [B*T, C] (row = one (sample,
+// timestep)); the reference's [B,C,T] (dilated_cnn.py:211) is never formed.
+// Per BatchNorm layer j (blocks and transitions interleaved, forward order) the
+// forward workspace keeps u_j (pre-BN convolution output) and a_j (the layer's
+// activation) for the backward pass, plus fp64 column statistics.
+//
+// Training-mode BatchNorm needs full-batch column statistics between the
+// convolution and its activation, so the driver is cut into phases at those
+// points: the convolution GEMM accumulates (sum, sum of squares) per channel in
+// its epilogue; the next phase finalises them (a data-parallel caller
+// all-reduces the fp64 block in between) and applies scale/shift + ReLU
+// (+ residual) in one elementwise pass.
+#include "../../include/ocean_hip.h"
+#include "ops.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+constexpr int kMaxBN = 2 * OCEAN_MAX_CONV_LAYERS - 1;
+
+struct DcnnPlan {
+  int M, L, nbn, cmax;
+  int width[kMaxBN], in_width[kMaxBN], is_block[kMaxBN], li[kMaxBN];
+  size_t h0, u[kMaxBN], a[kMaxBN], pooled;
+  size_t stats[kMaxBN], mean[kMaxBN], invstd[kMaxBN], scale[kMaxBN], shift[kMaxBN];
+  size_t wp[OCEAN_MAX_CONV_LAYERS];
+  size_t fwd_total;
+  size_t gA, gB, dU, dpool, bstats[kMaxBN], dwp[OCEAN_MAX_CONV_LAYERS], bwd_total;
+};
+
+inline size_t al4(size_t x) { return (x + 3) & ~size_t(3); }
+
+int make_plan(const ocean_dcnn_shape* s, DcnnPlan* p) {
+  if (!s) return OCEAN_ERR_NULL;
+  if (s->B <= 0 || s->T <= 0 || s->F <= 0 || s->L < 1 || s->L > OCEAN_MAX_CONV_LAYERS ||
+      s->out_dim <= 0 || s->kernel_size < 1 || (s->kernel_size & 1) == 0)
+    return OCEAN_ERR_BAD_SHAPE;
+  for (int i = 0; i < s->L; ++i)
+    if (s->channels[i] <= 0 || s->dilations[i] <= 0) return OCEAN_ERR_BAD_SHAPE;
+  p->M = s->B * s->T;
+  p->L = s->L;
+  p->nbn = 2 * s->L - 1;
+  p->cmax = 0;
+  const size_t M = (size_t)p->M;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o = al4(o + n); return r; };
+  p->h0 = take(M * s->channels[0]);
+  for (int j = 0; j < p->nbn; ++j) {
+    const int i = j / 2;
+    p->is_block[j] = (j % 2 == 0);
+    p->li[j] = i;
+    p->in_width[j] = s->channels[i];
+    p->width[j] = p->is_block[j] ? s->channels[i] : s->channels[i + 1];
+    if (p->width[j] > p->cmax) p->cmax = p->width[j];
+    p->u[j] = take(M * p->width[j]);
+    p->a[j] = take(M * p->width[j]);
+  }
+  p->pooled = take((size_t)s->B * s->channels[s->L - 1]);
+  for (int j = 0; j < p->nbn; ++j) {
+    const size_t C = p->width[j];
+    p->stats[j] = take(4 * C);   // 2*C doubles
+    p->mean[j] = take(C); p->invstd[j] = take(C); p->scale[j] = take(C); p->shift[j] = take(C);
+  }
+  for (int i = 0; i < s->L; ++i) p->wp[i] = take((size_t)s->kernel_size * s->channels[i] * s->channels[i]);
+  p->fwd_total = o;
+  o = 0;
+  p->gA = take(M * p->cmax); p->gB = take(M * p->cmax); p->dU = take(M * p->cmax);
+  p->dpool = take((size_t)s->B * s->channels[s->L - 1]);
+  for (int j = 0; j < p->nbn; ++j) p->bstats[j] = take(4 * (size_t)p->width[j]);
+  for (int i = 0; i < s->L; ++i) p->dwp[i] = take((size_t)s->kernel_size * s->channels[i] * s->channels[i]);
+  p->bwd_total = o;
+  return OCEAN_OK;
+}
+
+// parameter table indices
+inline int pi_block(int i, int k) { return 2 + 5 * i + k; }                 // k: 0 conv_w 1 bn_w 2 bn_b 3 rm 4 rv
+inline int pi_trans(int L, int i, int k) { return 2 + 5 * L + 5 * i + k; }
+inline int pi_out(int L, int k) { return 2 + 5 * L + 5 * (L - 1) + k; }
+inline int pi_bn(const DcnnPlan& p, int j, int k) { return p.is_block[j] ? pi_block(p.li[j], k) : pi_trans(p.L, p.li[j], k); }
+
+// ------------------------------------------------------------------ kernels
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double n, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift, int C, int training, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mu, var;
+  if (training) {
+    const double m = stats[c] / n;
+    double v = stats[C + c] / n - m * m;
+    if (v < 0.0) v = 0.0;
+    mu = (float)m; var = (float)v;
+    const double unbiased = n > 1.0 ? v * n / (n - 1.0) : v;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * mu;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unbiased;
+  } else {
+    mu = rm[c]; var = rv[c];
+  }
+  const float is = 1.0f / sqrtf(var + eps);
+  mean[c] = mu; invstd[c] = is;
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - mu * sc;
+}
+
+// out = dropout(relu(u*scale + shift)) (+ res)
+template <int VEC>
+__global__ void bn_apply_fwd_kernel(const float* __restrict__ u, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, const float* __restrict__ res,
+                                    float* __restrict__ out, long n, int C, DropoutP dp) {
+  for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * VEC; i < n; i += (long)gridDim.x * blockDim.x * VEC) {
+    const int c = (int)(i % C);
+    if (VEC == 4) {
+      const float4 x = *reinterpret_cast<const float4*>(u + i);
+      const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+      const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+      float4 y;
+      y.x = fmaxf(fmaf(x.x, sc.x, sh.x), 0.f); y.y = fmaxf(fmaf(x.y, sc.y, sh.y), 0.f);
+      y.z = fmaxf(fmaf(x.z, sc.z, sh.z), 0.f); y.w = fmaxf(fmaf(x.w, sc.w, sh.w), 0.f);
+      if (dp.p > 0.f) { y.x *= dropout_keep(dp, i); y.y *= dropout_keep(dp, i + 1); y.z *= dropout_keep(dp, i + 2); y.w *= dropout_keep(dp, i + 3); }
+      if (res) { const float4 r = *reinterpret_cast<const float4*>(res + i); y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w; }
+      *reinterpret_cast<float4*>(out + i) = y;
+    } else {
+      float y = fmaxf(fmaf(u[i], scale[c], shift[c]), 0.f);
+      if (dp.p > 0.f) y *= dropout_keep(dp, i);
+      if (res) y += res[i];
+      out[i] = y;
+    }
+  }
+}
+
+// Column sums of g and g*xhat, g = dy * (u*scale+shift > 0), xhat = (u-mean)*invstd.
+// Block = 64 column lanes x 4 row lanes; ROWS rows per block; fp64 atomics per column.
+constexpr int kRedRows = 256;
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int bcast_T, float dy_scale,
+                                                            const float* __restrict__ u, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, double* __restrict__ bstats,
+                                                            int M, int C, DropoutP dp) {
+  __shared__ float red[2][4][64 * VEC];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 64 + tx) * VEC;
+  const int r0 = blockIdx.y * kRedRows, r1 = min(M, r0 + kRedRows);
+  float sg[VEC], sx[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { sg[v] = 0.f; sx[v] = 0.f; }
+  if (c0 < C) {
+    float sc[VEC], sh[VEC], mu[VEC], is[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { sc[v] = scale[c0 + v]; sh[v] = shift[c0 + v]; mu[v] = mean[c0 + v]; is[v] = invstd[c0 + v]; }
+    for (int r = r0 + ty; r < r1; r += 4) {
+      float uu[VEC], gg[VEC];
+      const long ui = (long)r * C + c0;
+      const long gi = bcast_T > 0 ? (long)(r / bcast_T) * C + c0 : ui;
+      if (VEC == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(u + ui);
+        const float4 b = *reinterpret_cast<const float4*>(dy + gi);
+        uu[0] = a.x; uu[1 % VEC] = a.y; uu[2 % VEC] = a.z; uu[3 % VEC] = a.w;
+        gg[0] = b.x; gg[1 % VEC] = b.y; gg[2 % VEC] = b.z; gg[3 % VEC] = b.w;
+      } else { uu[0] = u[ui]; gg[0] = dy[gi]; }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float g = (fmaf(uu[v], sc[v], sh[v]) > 0.f) ? gg[v] * dy_scale : 0.f;
+        if (dp.p > 0.f) g *= dropout_keep(dp, ui + v);
+        sg[v] += g;
+        sx[v] += g * (uu[v] - mu[v]) * is[v];
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { red[0][ty][tx * VEC + v] = sg[v]; red[1][ty][tx * VEC + v] = sx[v]; }
+  __syncthreads();
+  if (ty == 0 && c0 < C) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float a = red[0][0][tx * VEC + v] + red[0][1][tx * VEC + v] + red[0][2][tx * VEC + v] + red[0][3][tx * VEC + v];
+      const float b = red[1][0][tx * VEC + v] + red[1][1][tx * VEC + v] + red[1][2][tx * VEC + v] + red[1][3][tx * VEC + v];
+      unsafeAtomicAdd(bstats + c0 + v, (double)a);
+      unsafeAtomicAdd(bstats + C + c0 + v, (double)b);
+    }
+  }
+}
+
+// du = gamma*invstd * (g - sum(g)/n - xhat*sum(g*xhat)/n)   (training)
+// du = g * scale                                            (eval: fixed statistics)
+template <int VEC>
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int bcast_T, float dy_scale, const float* __restrict__ u,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const double* __restrict__ bstats, double n, float* __restrict__ du,
+                                    long total, int C, int training, DropoutP dp) {
+  for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * VEC; i < total; i += (long)gridDim.x * blockDim.x * VEC) {
+    const int c = (int)(i % C);
+    const long r = i / C;
+    const long gi = bcast_T > 0 ? (r / bcast_T) * C + c : i;
+    float uu[VEC], gg[VEC], o[VEC];
+    if (VEC == 4) {
+      const float4 a = *reinterpret_cast<const float4*>(u + i);
+      const float4 b = *reinterpret_cast<const float4*>(dy + gi);
+      uu[0] = a.x; uu[1 % VEC] = a.y; uu[2 % VEC] = a.z; uu[3 % VEC] = a.w;
+      gg[0] = b.x; gg[1 % VEC] = b.y; gg[2 % VEC] = b.z; gg[3 % VEC] = b.w;
+    } else { uu[0] = u[i]; gg[0] = dy[gi]; }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float sc = scale[c + v];
+      float g = (fmaf(uu[v], sc, shift[c + v]) > 0.f) ? gg[v] * dy_scale : 0.f;
+      if (dp.p > 0.f) g *= dropout_keep(dp, i + v);
+      if (training) {
+        const float mg = (float)(bstats[c + v] / n), mgx = (float)(bstats[C + c + v] / n);
+        const float xh = (uu[v] - mean[c + v]) * invstd[c + v];
+        o[v] = sc * (g - mg - xh * mgx);
+      } else {
+        o[v] = g * sc;
+      }
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(du + i) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+    else du[i] = o[0];
+  }
+}
+
+__global__ void bn_bwd_param_kernel(const double* __restrict__ bstats, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] += (float)bstats[c];
+  if (dgamma) dgamma[c] += (float)bstats[C + c];
+}
+
+__global__ void mean_t_kernel(const float* __restrict__ a, float* __restrict__ out, int T, int C) {
+  const int b = blockIdx.x;
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float* p = a + (long)b * T * C + c;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += p[(long)t * C];
+  out[(long)b * C + c] = s / (float)T;
+}
+
+// [Co][Ci][Kt] -> [Kt][Co][Ci]
+__global__ void repack_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int Kt) {
+  const long n = (long)Co * Ci * Kt;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % Kt);
+    const long oc = i / Kt;          // co*Ci + ci
+    wp[(long)t * Co * Ci + oc] = w[i];
+  }
+}
+// dw[Co][Ci][Kt] += dwp[Kt][Co][Ci]
+__global__ void unpack_dw_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int Kt) {
+  const long n = (long)Co * Ci * Kt;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % Kt);
+    const long oc = i / Kt;
+    dw[i] += dwp[(long)t * Co * Ci + oc];
+  }
+}
+
+inline int egrid(long n, int per = 256) {
+  long g = (n + per - 1) / per;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int bn_finalize(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, float* const* params, float* ws, hipStream_t st) {
+  const int C = pl.width[j];
+  const double n = (double)(s->bn_count > 0 ? s->bn_count : pl.M);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st,
+                     reinterpret_cast<const double*>(ws + pl.stats[j]), n, params[pi_bn(pl, j, 1)], params[pi_bn(pl, j, 2)],
+                     params[pi_bn(pl, j, 3)], params[pi_bn(pl, j, 4)], ws + pl.mean[j], ws + pl.invstd[j],
+                     ws + pl.scale[j], ws + pl.shift[j], C, s->training, s->eps, s->momentum);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+inline DropoutP layer_dropout(const ocean_dcnn_shape* s, int j) {
+  DropoutP dp;
+  dp.p = s->training ? s->dropout : 0.f;
+  dp.seed = s->seed + 0x9E3779B97F4A7C15ull * (uint64_t)(j + 1);
+  return dp;
+}
+
+int bn_apply_fwd(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, float* ws, const float* res, hipStream_t st) {
+  const int C = pl.width[j];
+  const DropoutP dp = layer_dropout(s, j);
+  const long n = (long)pl.M * C;
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<4>, dim3(egrid(n / 4)), dim3(256), 0, st, ws + pl.u[j], ws + pl.scale[j],
+                       ws + pl.shift[j], res, ws + pl.a[j], n, C, dp);
+  else
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<1>, dim3(egrid(n)), dim3(256), 0, st, ws + pl.u[j], ws + pl.scale[j],
+                       ws + pl.shift[j], res, ws + pl.a[j], n, C, dp);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+// the convolution of BN layer j: input activation -> u_j, column statistics in the epilogue
+int conv_fwd(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, const float* in, float* const* params, float* ws, hipStream_t st) {
+  GemmP g = gemm_defaults();
+  g.A = in; g.lda = pl.in_width[j]; g.C = ws + pl.u[j]; g.ldc = pl.width[j];
+  g.M = pl.M; g.N = pl.width[j]; g.K = pl.in_width[j];
+  g.colstats = s->training ? reinterpret_cast<double*>(ws + pl.stats[j]) : nullptr;
+  if (pl.is_block[j]) {
+    const int i = pl.li[j], k = s->kernel_size;
+    g.B = ws + pl.wp[i]; g.ldb = pl.in_width[j];
+    if (k > 1) {
+      g.taps = k; g.T = s->T; g.shift0 = -(k / 2) * s->dilations[i]; g.shift_step = s->dilations[i];
+      g.tap_stride_b = (long)pl.width[j] * pl.in_width[j];
+    }
+  } else {
+    g.B = params[pi_trans(pl.L, pl.li[j], 0)]; g.ldb = pl.in_width[j];
+  }
+  return ocean_launch_gemm(g, st);
+}
+
+const float* layer_input(const DcnnPlan& pl, int j, const float* ws) { return j == 0 ? ws + pl.h0 : ws + pl.a[j - 1]; }
+
+}  // namespace
+
+extern "C" {
+
+size_t ocean_dcnn_param_count(const ocean_dcnn_shape* s) { return s ? (size_t)(2 + 5 * s->L + 5 * (s->L - 1) + 2) : 0; }
+
+size_t ocean_dcnn_fwd_workspace(const ocean_dcnn_shape* s) {
+  DcnnPlan p;
+  return make_plan(s, &p) == OCEAN_OK ? p.fwd_total : 0;
+}
+size_t ocean_dcnn_bwd_workspace(const ocean_dcnn_shape* s) {
+  DcnnPlan p;
+  return make_plan(s, &p) == OCEAN_OK ? p.bwd_total : 0;
+}
+int ocean_dcnn_num_phases(const ocean_dcnn_shape* s) { return s ? 2 * s->L : 0; }
+
+int ocean_dcnn_stats_block(const ocean_dcnn_shape* s, int phase, int backward, size_t* offset_floats, int* n_doubles) {
+  DcnnPlan p;
+  OCEAN_TRY(make_plan(s, &p));
+  if (phase < 0 || phase >= p.nbn) return OCEAN_ERR_BAD_SHAPE;
+  // forward phase j completes stats of BN layer j; backward phase j completes layer nbn-1-j
+  const int j = backward ? p.nbn - 1 - phase : phase;
+  if (offset_floats) *offset_floats = backward ? p.bstats[j] : p.stats[j];
+  if (n_doubles) *n_doubles = 2 * p.width[j];
+  return OCEAN_OK;
+}
+
+int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* params, float* ws, size_t ws_floats,
+                   float* out, int phase_lo, int phase_hi, void* stream) {
+  DcnnPlan pl;
+  OCEAN_TRY(make_plan(s, &pl));
+  if (!x || !params || !ws || !out) return OCEAN_ERR_NULL;
+  if (ws_floats < pl.fwd_total) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int L = s->L, nph = 2 * L;
+  if (phase_lo < 0) phase_lo = 0;
+  if (phase_hi > nph) phase_hi = nph;
+  for (int ph = phase_lo; ph < phase_hi; ++ph) {
+    if (ph == 0) {
+      if (s->training) OCEAN_TRY(zero_f32(ws + pl.stats[0], pl.wp[0] - pl.stats[0], st));
+      for (int i = 0; i < L; ++i) {
+        const int C = s->channels[i];
+        hipLaunchKernelGGL(repack_w_kernel, dim3(egrid((long)C * C * s->kernel_size)), dim3(256), 0, st,
+                           params[pi_block(i, 0)], ws + pl.wp[i], C, C, s->kernel_size);
+        OCEAN_LAUNCH_CHECK();
+      }
+      OCEAN_TRY(linear_fwd(x, s->F, params[0], params[1], ws + pl.h0, s->channels[0], pl.M, s->channels[0], s->F, 0, st));
+      OCEAN_TRY(conv_fwd(pl, s, 0, ws + pl.h0, params, ws, st));
+    } else {
+      const int j = ph - 1;   // finish BN layer j
+      OCEAN_TRY(bn_finalize(pl, s, j, params, ws, st));
+      OCEAN_TRY(bn_apply_fwd(pl, s, j, ws, pl.is_block[j] ? layer_input(pl, j, ws) : nullptr, st));
+      if (ph < nph - 1) {
+        OCEAN_TRY(conv_fwd(pl, s, j + 1, ws + pl.a[j], params, ws, st));
+      } else {
+        const int C = s->channels[L - 1];
+        hipLaunchKernelGGL(mean_t_kernel, dim3(s->B, ceil_div(C, 256)), dim3(256), 0, st, ws + pl.a[j], ws + pl.pooled, s->T, C);
+        OCEAN_LAUNCH_CHECK();
+        OCEAN_TRY(linear_fwd(ws + pl.pooled, C, params[pi_out(L, 0)], params[pi_out(L, 1)], out, s->out_dim, s->B, s->out_dim, C, 0, st));
+      }
+    }
+  }
+  return OCEAN_OK;
+}
+
+int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* params, float* wf, float* wb, size_t wb_floats,
+                   const float* dout, float* const* grads, float* dx, int phase_lo, int phase_hi, void* stream) {
+  DcnnPlan pl;
+  OCEAN_TRY(make_plan(s, &pl));
+  if (!x || !params || !wf || !wb || !dout || !grads) return OCEAN_ERR_NULL;
+  if (wb_floats < pl.bwd_total) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int L = s->L, nph = 2 * L, M = pl.M;
+  const double n = (double)(s->bn_count > 0 ? s->bn_count : pl.M);
+  if (phase_lo < 0) phase_lo = 0;
+  if (phase_hi > nph) phase_hi = nph;
+  const int Cl = s->channels[L - 1];
+
+  // which gradient buffer holds d(a_j) when BN layer j is processed: layers are
+  // walked from the last to the first; a block keeps the buffer (in-place
+  // residual), a transition flips it.
+  auto grad_buf = [&](int j) {
+    int flips = 0;
+    for (int q = pl.nbn - 1; q > j; --q) if (!pl.is_block[q]) ++flips;
+    return (flips & 1) ? wb + pl.gB : wb + pl.gA;
+  };
+
+  auto reduce = [&](int j) -> int {
+    const int C = pl.width[j];
+    const bool last = (j == pl.nbn - 1);
+    const float* dy = last ? wb + pl.dpool : grad_buf(j);
+    const int bT = last ? s->T : 0;
+    const float sc = last ? 1.0f / (float)s->T : 1.0f;
+    double* bs = reinterpret_cast<double*>(wb + pl.bstats[j]);
+    if (C % 4 == 0) {
+      dim3 grid(ceil_div(C, 256), ceil_div(M, kRedRows));
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, st, dy, bT, sc, wf + pl.u[j], wf + pl.scale[j],
+                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, M, C, layer_dropout(s, j));
+    } else {
+      dim3 grid(ceil_div(C, 64), ceil_div(M, kRedRows));
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, st, dy, bT, sc, wf + pl.u[j], wf + pl.scale[j],
+                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, M, C, layer_dropout(s, j));
+    }
+    OCEAN_LAUNCH_CHECK();
+    return OCEAN_OK;
+  };
+
+  for (int ph = phase_lo; ph < phase_hi; ++ph) {
+    if (ph == 0) {
+      OCEAN_TRY(zero_f32(wb + pl.bstats[0], pl.bwd_total - pl.bstats[0], st));   // bstats + packed weight grads
+      // output projection
+      OCEAN_TRY(linear_bwd_weight(dout, s->out_dim, wf + pl.pooled, Cl, grads[pi_out(L, 0)], s->B, s->out_dim, Cl, st));
+      OCEAN_TRY(colsum_add(dout, s->out_dim, s->B, s->out_dim, grads[pi_out(L, 1)], st));
+      OCEAN_TRY(linear_bwd_data(dout, s->out_dim, params[pi_out(L, 0)], wb + pl.dpool, Cl, s->B, s->out_dim, Cl, 0, st));
+      OCEAN_TRY(reduce(pl.nbn - 1));
+      continue;
+    }
+    const int j = pl.nbn - ph;          // BN layer finished in this phase
+    const int C = pl.width[j], Cin = pl.in_width[j];
+    const bool last = (j == pl.nbn - 1);
+    const float* dy = last ? wb + pl.dpool : grad_buf(j);
+    const int bT = last ? s->T : 0;
+    const float dsc = last ? 1.0f / (float)s->T : 1.0f;
+    const double* bs = reinterpret_cast<const double*>(wb + pl.bstats[j]);
+    float* dU = wb + pl.dU;
+    const long tot = (long)M * C;
+    if (C % 4 == 0)
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(egrid(tot / 4)), dim3(256), 0, st, dy, bT, dsc, wf + pl.u[j], wf + pl.scale[j],
+                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, n, dU, tot, C, s->training, layer_dropout(s, j));
+    else
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(egrid(tot)), dim3(256), 0, st, dy, bT, dsc, wf + pl.u[j], wf + pl.scale[j],
+                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, n, dU, tot, C, s->training, layer_dropout(s, j));
+    OCEAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_param_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st, bs, grads[pi_bn(pl, j, 1)], grads[pi_bn(pl, j, 2)], C);
+    OCEAN_LAUNCH_CHECK();
+    const float* in = layer_input(pl, j, wf);
+    if (pl.is_block[j]) {
+      const int i = pl.li[j], k = s->kernel_size, d = s->dilations[i];
+      // weight gradient per tap into the packed buffer
+      GemmP g = gemm_defaults();
+      g.A = dU; g.lda = C; g.a_kmajor = 1; g.B = in; g.ldb = Cin; g.b_kn = 1;
+      g.C = wb + pl.dwp[i]; g.ldc = Cin; g.M = C; g.N = Cin; g.K = M; g.split_k = 0;
+      g.taps = k; g.tap_stride_c = (long)C * Cin;
+      if (k > 1) { g.T = s->T; g.shift0 = -(k / 2) * d; g.shift_step = d; }
+      OCEAN_TRY(ocean_launch_gemm(g, st));
+      hipLaunchKernelGGL(unpack_dw_kernel, dim3(egrid((long)C * Cin * k)), dim3(256), 0, st, wb + pl.dwp[i], grads[pi_block(i, 0)], C, Cin, k);
+      OCEAN_LAUNCH_CHECK();
+      // data gradient: taps with the opposite shift, plus the identity-residual gradient
+      GemmP h = gemm_defaults();
+      h.A = dU; h.lda = C; h.B = wf + pl.wp[i]; h.ldb = Cin; h.b_kn = 1; h.M = M; h.N = Cin; h.K = C;
+      if (k > 1) { h.taps = k; h.T = s->T; h.shift0 = (k / 2) * d; h.shift_step = -d; h.tap_stride_b = (long)C * Cin; }
+      float* gout = grad_buf(j);          // same buffer: d(input) = conv^T(dU) + d(output)
+      h.C = gout; h.ldc = Cin;
+      if (last) { h.R = wb + pl.dpool; h.ldr = Cl; h.r_bcast_T = s->T; h.r_scale = 1.0f / (float)s->T; }
+      else { h.R = gout; h.ldr = Cin; }
+      OCEAN_TRY(ocean_launch_gemm(h, st));
+    } else {
+      const int i = pl.li[j];
+      OCEAN_TRY(linear_bwd_weight(dU, C, in, Cin, grads[pi_trans(L, i, 0)], M, C, Cin, st));
+      OCEAN_TRY(linear_bwd_data(dU, C, params[pi_trans(L, i, 0)], grad_buf(j - 1), Cin, M, C, Cin, 0, st));
+    }
+    if (j > 0) {
+      OCEAN_TRY(reduce(j - 1));
+    } else {
+      // input projection: grad wrt h0 sits in grad_buf(0)
+      const float* dh0 = grad_buf(0);
+      const int C0 = s->channels[0];
+      OCEAN_TRY(linear_bwd_weight(dh0, C0, x, s->F, grads[0], M, C0, s->F, st));
+      OCEAN_TRY(colsum_add(dh0, C0, M, C0, grads[1], st));
+      if (dx) OCEAN_TRY(linear_bwd_data(dh0, C0, params[0], dx, s->F, M, C0, s->F, 0, st));
+    }
+  }
+  return OCEAN_OK;
+}
+
+}  // extern "C"

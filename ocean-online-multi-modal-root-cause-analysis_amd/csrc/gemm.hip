@@ -1,0 +1,334 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
+// multiply-accumulate, 16 accumulator registers per 32x32 tile).
+//
+// One kernel template serves every dense contraction of the OCEAN step:
+//   nn.Linear forward (A[m][k] . W[n][k]), its data gradient (dY[m][k] . W[k][n])
+//   and weight gradient (dY[k][m]^T . X[k][n], reduction over rows, split-K with
+//   atomics), and the dilated Conv1d as an implicit GEMM over channels-last
+//   [B*T, C] activations: tap t reads rows shifted by (t - taps/2)*dilation with
+//   zero fill outside each sample's [0,T) window.
+//
+// Tiling: 256 threads = 4 waves in a 2x2 arrangement; each wave owns
+// (BM/2)x(BN/2) of the block tile as TMxTN 32x32 MFMA tiles.  Operand tiles are
+// staged k-major in LDS (As[k][m], Bs[k][n]) so that a fragment read is one
+// conflict-free ds_read_b32 per lane (lane l reads element [k=2s+(l>>5)][l&31]).
+// Tiles whose global storage is k-contiguous are transposed on the LDS write;
+// the row pad (32/BK floats) makes those scattered writes conflict-free.
+// Global loads for tile i+1 are issued before the MFMAs of tile i (register
+// prefetch) and written to the other LDS buffer afterwards: one barrier per tile.
+#include "common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ int xcd_swizzle(int orig, int nwg) {
+  // Blocks b and b+8 share an XCD (round-robin dispatch).  Give each XCD a
+  // contiguous run of tile ids so neighbouring tiles (same A panel) share an L2.
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (orig >> 3);
+}
+
+template <int BM, int BN, int BK, bool AKM, bool BKN, bool ALIGNED>
+__global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmP p) {
+  constexpr int WN = 2;
+  constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
+  constexpr int PADT = 32 / BK;
+  constexpr int LDA = BM + (AKM ? 4 : PADT);
+  constexpr int LDB = BN + (BKN ? 4 : PADT);
+  constexpr int A_F4 = BM * BK / 4 / kThreads;
+  constexpr int B_F4 = BN * BK / 4 / kThreads;
+  static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for 256 threads");
+  __shared__ __align__(16) float smem[2 * BK * (LDA + LDB)];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nwg = tiles_m * tiles_n;
+  const int bid = xcd_swizzle(blockIdx.x, nwg);
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // reduction range / tap handled by this block
+  int k_begin = 0, k_end = p.K, ztap = 0;
+  if (AKM) {
+    const int split = p.split_k > 0 ? p.split_k : 1;
+    ztap = blockIdx.z / split;
+    const int zs = blockIdx.z % split;
+    int chunk = (p.K + split - 1) / split;
+    chunk = (chunk + BK - 1) / BK * BK;
+    k_begin = zs * chunk;
+    k_end = min(p.K, k_begin + chunk);
+    if (k_begin >= k_end) return;
+  }
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  const int n_iter = (AKM ? 1 : p.taps) * nk;
+
+  // per-thread load coordinates that do not change over the reduction
+  int a_row[A_F4], a_col[A_F4], a_t[A_F4];
+  int b_row[B_F4], b_col[B_F4], b_t[B_F4];
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    const int idx = tid + i * kThreads;
+    if (AKM) { a_row[i] = idx / (BM / 4); a_col[i] = (idx % (BM / 4)) * 4; a_t[i] = 0; }
+    else {
+      a_row[i] = idx / (BK / 4); a_col[i] = (idx % (BK / 4)) * 4;
+      a_t[i] = (p.T > 0) ? (m0 + a_row[i]) % p.T : 0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i) {
+    const int idx = tid + i * kThreads;
+    if (BKN) { b_row[i] = idx / (BN / 4); b_col[i] = (idx % (BN / 4)) * 4; }
+    else { b_row[i] = idx / (BK / 4); b_col[i] = (idx % (BK / 4)) * 4; }
+    b_t[i] = 0;
+  }
+
+  float4 ra[A_F4], rb[B_F4];
+
+  auto load_tiles = [&](int it) {
+    const int tap = AKM ? ztap : it / nk;
+    const int kk0 = k_begin + (it % nk) * BK;
+    const int shift = (p.T > 0) ? p.shift0 + tap * p.shift_step : 0;
+    // ---- A
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (AKM) {                       // stored [k][m]: vector along m
+        const int gk = kk0 + a_row[i], gm = m0 + a_col[i];
+        if (gk < k_end) {
+          const float* src = p.A + (long)gk * p.lda + gm;
+          if (ALIGNED) { if (gm < p.M) v = *reinterpret_cast<const float4*>(src); }
+          else {
+            if (gm + 0 < p.M) v.x = src[0];
+            if (gm + 1 < p.M) v.y = src[1];
+            if (gm + 2 < p.M) v.z = src[2];
+            if (gm + 3 < p.M) v.w = src[3];
+          }
+        }
+      } else {                         // stored [m][k]: vector along k, row-shifted
+        const int gm = m0 + a_row[i], gk = kk0 + a_col[i];
+        const bool ok = gm < p.M && (p.T == 0 || (unsigned)(a_t[i] + shift) < (unsigned)p.T);
+        if (ok) {
+          const float* src = p.A + (long)(gm + shift) * p.lda + gk;
+          if (ALIGNED) { if (gk < k_end) v = *reinterpret_cast<const float4*>(src); }
+          else {
+            if (gk + 0 < k_end) v.x = src[0];
+            if (gk + 1 < k_end) v.y = src[1];
+            if (gk + 2 < k_end) v.z = src[2];
+            if (gk + 3 < k_end) v.w = src[3];
+          }
+        }
+      }
+      ra[i] = v;
+    }
+    // ---- B
+    const float* Bt = p.B + (AKM ? 0 : (long)tap * p.tap_stride_b);
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BKN) {                       // stored [k][n]: vector along n; rows shifted only when reducing over rows
+        const int gk = kk0 + b_row[i], gn = n0 + b_col[i];
+        bool ok = gk < k_end;
+        int srow = gk;
+        if (AKM && p.T > 0) {
+          const int t = gk % p.T;
+          ok = ok && (unsigned)(t + shift) < (unsigned)p.T;
+          srow = gk + shift;
+        }
+        if (ok) {
+          const float* src = Bt + (long)srow * p.ldb + gn;
+          if (ALIGNED) { if (gn < p.N) v = *reinterpret_cast<const float4*>(src); }
+          else {
+            if (gn + 0 < p.N) v.x = src[0];
+            if (gn + 1 < p.N) v.y = src[1];
+            if (gn + 2 < p.N) v.z = src[2];
+            if (gn + 3 < p.N) v.w = src[3];
+          }
+        }
+      } else {                         // stored [n][k]: vector along k
+        const int gn = n0 + b_row[i], gk = kk0 + b_col[i];
+        if (gn < p.N) {
+          const float* src = Bt + (long)gn * p.ldb + gk;
+          if (ALIGNED) { if (gk < k_end) v = *reinterpret_cast<const float4*>(src); }
+          else {
+            if (gk + 0 < k_end) v.x = src[0];
+            if (gk + 1 < k_end) v.y = src[1];
+            if (gk + 2 < k_end) v.z = src[2];
+            if (gk + 3 < k_end) v.w = src[3];
+          }
+        }
+      }
+      rb[i] = v;
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    float* Ad = As + buf * BK * LDA;
+    float* Bd = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+      if (AKM) *reinterpret_cast<float4*>(Ad + a_row[i] * LDA + a_col[i]) = ra[i];
+      else {
+        Ad[(a_col[i] + 0) * LDA + a_row[i]] = ra[i].x;
+        Ad[(a_col[i] + 1) * LDA + a_row[i]] = ra[i].y;
+        Ad[(a_col[i] + 2) * LDA + a_row[i]] = ra[i].z;
+        Ad[(a_col[i] + 3) * LDA + a_row[i]] = ra[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+      if (BKN) *reinterpret_cast<float4*>(Bd + b_row[i] * LDB + b_col[i]) = rb[i];
+      else {
+        Bd[(b_col[i] + 0) * LDB + b_row[i]] = rb[i].x;
+        Bd[(b_col[i] + 1) * LDB + b_row[i]] = rb[i].y;
+        Bd[(b_col[i] + 2) * LDB + b_row[i]] = rb[i].z;
+        Bd[(b_col[i] + 3) * LDB + b_row[i]] = rb[i].w;
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  const int a_frag = wm * (BM / 2) + (lane & 31);
+  const int b_frag = wn * (BN / 2) + (lane & 31);
+  const int khalf = lane >> 5;
+
+  for (int it = 0; it < n_iter; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < n_iter) load_tiles(it + 1);
+    const float* Ac = As + buf * BK * LDA + a_frag;
+    const float* Bc = Bs + buf * BK * LDB + b_frag;
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = Ac[(2 * s + khalf) * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bc[(2 * s + khalf) * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (it + 1 < n_iter) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------ epilogue
+  // acc register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile.
+  float* Cz = p.C + (AKM ? (long)ztap * p.tap_stride_c : 0);
+  const bool atomic_out = AKM;   // row-reduction outputs always accumulate (C += ...)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+    const bool col_ok = col < p.N;
+    if (p.colstats != nullptr) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s += v; q += v * v; }
+      s += __shfl_xor(s, 32);
+      q += __shfl_xor(q, 32);
+      if (lane < 32 && col_ok) {
+        unsafeAtomicAdd(p.colstats + col, (double)s);
+        unsafeAtomicAdd(p.colstats + p.N + col, (double)q);
+      }
+    }
+    const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * khalf;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2);
+        if (row < p.M && col_ok) {
+          float v = acc[i][j][r] + bias;
+          if (atomic_out) {
+            unsafeAtomicAdd(Cz + (long)row * p.ldc + col, v);
+          } else {
+            if (p.R != nullptr) {
+              if (p.r_bcast_T > 0) v += p.r_scale * p.R[(long)(row / p.r_bcast_T) * p.ldr + col];
+              else v += p.R[(long)row * p.ldr + col];
+            }
+            if (p.relu) v = fmaxf(v, 0.f);
+            Cz[(long)row * p.ldc + col] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int BK, bool AKM, bool BKN>
+int launch_cfg(const GemmP& p, bool aligned, hipStream_t stream) {
+  const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+  dim3 grid(tiles, 1, AKM ? p.taps * (p.split_k > 0 ? p.split_k : 1) : 1);
+  if (aligned) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, true>), grid, dim3(kThreads), 0, stream, p);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, false>), grid, dim3(kThreads), 0, stream, p);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+template <bool AKM, bool BKN>
+int launch_mode(GemmP p, bool aligned, hipStream_t stream) {
+  constexpr int BK = 16;
+  // tile choice: wide tiles only when they still fill the chip
+  const bool big_m = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128) >= 256;
+  int bm, bn;
+  if (p.N > 64 && big_m) { bm = 128; bn = 128; }
+  else if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 256) { bm = 128; bn = 64; }
+  else { bm = 64; bn = 64; }
+  if (AKM && p.split_k <= 0) {
+    // reduction over rows: split so that the launch has >= ~3 blocks per CU
+    const long blocks = (long)ceil_div(p.M, bm) * ceil_div(p.N, bn) * p.taps;
+    long want = (768 + blocks - 1) / blocks;
+    const long max_split = (p.K + 255) / 256;    // >= 256 reduction rows per block
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    p.split_k = (int)want;
+  }
+  if (bm == 128 && bn == 128) return launch_cfg<128, 128, BK, AKM, BKN>(p, aligned, stream);
+  if (bm == 128 && bn == 64) return launch_cfg<128, 64, BK, AKM, BKN>(p, aligned, stream);
+  return launch_cfg<64, 64, BK, AKM, BKN>(p, aligned, stream);
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+int ocean_launch_gemm(const GemmP& p, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.taps < 1) return OCEAN_ERR_BAD_SHAPE;
+  if (!p.A || !p.B || !p.C) return OCEAN_ERR_NULL;
+  if (p.a_kmajor && !p.b_kn) return OCEAN_ERR_UNSUPPORTED;
+  if (p.taps > 1 && p.T <= 0) return OCEAN_ERR_BAD_SHAPE;
+  // vector (16-byte) loads need every row start and every in-range 4-group aligned
+  bool aligned = al16(p.A) && al16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
+                 p.tap_stride_b % 4 == 0;
+  if (p.a_kmajor) aligned = aligned && p.M % 4 == 0 && p.N % 4 == 0;
+  else if (p.b_kn) aligned = aligned && p.K % 4 == 0 && p.N % 4 == 0;
+  else aligned = aligned && p.K % 4 == 0;
+  if (p.a_kmajor) return launch_mode<true, true>(p, aligned, stream);
+  if (p.b_kn) return launch_mode<false, true>(p, aligned, stream);
+  return launch_mode<false, false>(p, aligned, stream);
+}

@@ -1,0 +1,22 @@
+// Internal (C++) building blocks shared by the component drivers.
+#pragma once
+#include "common.h"
+
+// y[M,N] = x[M,K] . W[N,K]^T (+ b) (ReLU)                (nn.Linear forward)
+int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy,
+               int M, int N, int K, int relu, hipStream_t s);
+// dx[M,K] (+= if accumulate) = dy[M,N] . W[N,K]          (nn.Linear data gradient)
+int linear_bwd_data(const float* dy, int lddy, const float* W, float* dx, int lddx,
+                    int M, int N, int K, int accumulate, hipStream_t s);
+// dW[N,K] += dy[M,N]^T . x[M,K]                          (nn.Linear weight gradient, atomic accumulate)
+int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float* dW,
+                      int M, int N, int K, hipStream_t s);
+// out[N] += column sums of a[M,N]                         (bias gradients)
+int colsum_add(const float* a, int lda, int M, int N, float* out, hipStream_t s);
+// dy[i] = (y[i] > 0) ? dy[i] : 0   over an [M,N] matrix with leading dims    (ReLU backward on the saved output)
+int relu_bwd_inplace(float* dy, int lddy, const float* y, int ldy, int M, int N, hipStream_t s);
+// dst = 0
+int zero_f32(float* dst, size_t n, hipStream_t s);
+int zero_f64(double* dst, size_t n, hipStream_t s);
+// dst[M,N] (ld) = src[M,N] (ld) ; or dst += src
+int copy2d(float* dst, int ldd, const float* src, int lds, int M, int N, int accumulate, hipStream_t s);

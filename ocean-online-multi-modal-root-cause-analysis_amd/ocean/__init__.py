@@ -1,0 +1,3 @@
+"""OCEAN (Online multi-modal Causal structure lEArNiNG) per-step model hot path
+on AMD MI355X: the reference's Python API over hand-written gfx950 kernels."""
+__version__ = "0.1.0"

@@ -1,0 +1,114 @@
+"""ctypes binding of libocean_hip.so (the C ABI declared in include/ocean_hip.h).
+
+This module is plumbing only: it loads the shared library, declares the
+signatures, converts torch tensors to device pointers and turns status codes
+into exceptions.  There is no CPU fallback: every op raises if the library is
+missing or a tensor is not a contiguous fp32 CUDA tensor.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_double, c_float, c_int, c_long, c_size_t, c_uint64, c_void_p
+from typing import Optional, Sequence
+
+import torch
+
+MAX_CONV_LAYERS = 8
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libocean_hip.so")
+_lib = None
+
+_STATUS = {1: "bad shape", 2: "unsupported size", 3: "workspace too small", 4: "null pointer"}
+
+
+class OceanHipError(RuntimeError):
+    pass
+
+
+class DcnnShape(ctypes.Structure):
+    _fields_ = [("B", c_int), ("T", c_int), ("F", c_int), ("L", c_int),
+                ("channels", c_int * MAX_CONV_LAYERS), ("dilations", c_int * MAX_CONV_LAYERS),
+                ("kernel_size", c_int), ("out_dim", c_int), ("training", c_int),
+                ("eps", c_float), ("momentum", c_float), ("bn_count", c_long),
+                ("dropout", c_float), ("seed", c_uint64)]
+
+
+def _declare(lib) -> None:
+    fp = POINTER(c_float)
+    lib.ocean_abi_version.restype = c_int
+    lib.ocean_gemm_f32.restype = c_int
+    lib.ocean_gemm_f32.argtypes = [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]
+    sp = POINTER(DcnnShape)
+    lib.ocean_dcnn_param_count.restype = c_size_t
+    lib.ocean_dcnn_param_count.argtypes = [sp]
+    lib.ocean_dcnn_fwd_workspace.restype = c_size_t
+    lib.ocean_dcnn_fwd_workspace.argtypes = [sp]
+    lib.ocean_dcnn_bwd_workspace.restype = c_size_t
+    lib.ocean_dcnn_bwd_workspace.argtypes = [sp]
+    lib.ocean_dcnn_num_phases.restype = c_int
+    lib.ocean_dcnn_num_phases.argtypes = [sp]
+    lib.ocean_dcnn_stats_block.restype = c_int
+    lib.ocean_dcnn_stats_block.argtypes = [sp, c_int, c_int, POINTER(c_size_t), POINTER(c_int)]
+    lib.ocean_dcnn_fwd.restype = c_int
+    lib.ocean_dcnn_fwd.argtypes = [sp, c_void_p, POINTER(c_void_p), c_void_p, c_size_t, c_void_p, c_int, c_int, c_void_p]
+    lib.ocean_dcnn_bwd.restype = c_int
+    lib.ocean_dcnn_bwd.argtypes = [sp, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_size_t, c_void_p,
+                                   POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p]
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise OceanHipError(
+                f"{_LIB_PATH} is missing: build it with `make -C <package>/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status == 0:
+        return
+    if status >= 1000:
+        raise OceanHipError(f"{what}: HIP error {status - 1000}")
+    raise OceanHipError(f"{what}: {_STATUS.get(status, 'status ' + str(status))}")
+
+
+def dev_ptr(t: Optional[torch.Tensor], name: str = "tensor", dtype=torch.float32) -> c_void_p:
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise OceanHipError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise OceanHipError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous():
+        raise OceanHipError(f"{name} must be contiguous")
+    return c_void_p(t.data_ptr())
+
+
+def ptr_table(tensors: Sequence[Optional[torch.Tensor]], name: str):
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = dev_ptr(t, f"{name}[{i}]").value if t is not None else None
+    return arr
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, lda=None, ldb=None,
+         ldc=None, a_kmajor=False, b_kn=False, bias=None, residual=None, ldr=0, relu=False) -> torch.Tensor:
+    """Raw GEMM entry (tests and small glue): see ocean_gemm_f32."""
+    lda = lda if lda is not None else (M if a_kmajor else K)
+    ldb = ldb if ldb is not None else (N if b_kn else K)
+    ldc = ldc if ldc is not None else N
+    st = lib().ocean_gemm_f32(dev_ptr(a, "A"), lda, dev_ptr(b, "B"), ldb, dev_ptr(out, "C"), ldc, M, N, K,
+                              int(a_kmajor), int(b_kn), dev_ptr(bias, "bias"), dev_ptr(residual, "R"),
+                              ldr or ldc, int(relu), stream())
+    check(st, "ocean_gemm_f32")
+    return out

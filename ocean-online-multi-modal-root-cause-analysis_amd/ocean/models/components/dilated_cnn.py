@@ -1,0 +1,222 @@
+"""Temporal encoder: stacked dilated Conv1d blocks over metric windows, on MI355X.
+
+Interface and state_dict keys follow the reference's DilatedCNN /
+DilatedConvBlock (ocean/models/components/dilated_cnn.py:16-99, 102-241); the
+torch sub-modules held here (nn.Linear / nn.Conv1d / nn.BatchNorm1d) are
+parameter containers only - their forward() is never called.  The arithmetic
+runs in libocean_hip.so (ocean_dcnn_fwd / ocean_dcnn_bwd): channels-last
+activations, every convolution an fp32-MFMA implicit GEMM, BatchNorm
+statistics accumulated in the GEMM epilogue.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, List, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import _hip
+
+_ACTIVATIONS = ("relu", "gelu", "leaky_relu")
+
+
+class DilatedConvBlock(nn.Module):
+    """conv(k, dilation, 'same' symmetric padding, no bias) -> BatchNorm -> ReLU
+    -> Dropout, plus the identity residual (dilated_cnn.py:76-99).  Container
+    for one block's parameters; DilatedCNN drives the kernels."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, dilation: int = 1,
+                 dropout: float = 0.1, activation: str = "relu"):
+        super().__init__()
+        if activation not in _ACTIVATIONS:
+            raise ValueError(f"Unsupported activation: {activation}")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.dilation = kernel_size, dilation
+        self.activation_name = activation
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, dilation=dilation,
+                              padding=(kernel_size - 1) * dilation // 2, bias=False)
+        self.batch_norm = nn.BatchNorm1d(out_channels)
+        self.dropout = nn.Dropout(dropout)
+        self.use_residual = in_channels == out_channels
+        if not self.use_residual:
+            self.residual_conv = nn.Conv1d(in_channels, out_channels, kernel_size=1, bias=False)
+            self.residual_bn = nn.BatchNorm1d(out_channels)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError(
+            "DilatedConvBlock is executed by DilatedCNN's fused HIP driver; call the parent DilatedCNN")
+
+
+class _DcnnFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, *params):
+        L = _hip.lib()
+        shape = module._shape(x)
+        B = shape.B
+        ws = torch.empty(L.ocean_dcnn_fwd_workspace(ctypes.byref(shape)), device=x.device, dtype=torch.float32)
+        out = torch.empty(B, shape.out_dim, device=x.device, dtype=torch.float32)
+        ptab = _hip.ptr_table(params, "dcnn param")
+        nph = L.ocean_dcnn_num_phases(ctypes.byref(shape))
+        sync = module.stats_all_reduce if shape.training else None
+
+        def run(lo, hi):
+            _hip.check(L.ocean_dcnn_fwd(ctypes.byref(shape), _hip.dev_ptr(x, "metrics"), ptab, _hip.dev_ptr(ws),
+                                        ws.numel(), _hip.dev_ptr(out), lo, hi, _hip.stream()), "ocean_dcnn_fwd")
+        if sync is None:
+            run(0, nph)
+        else:
+            for ph in range(nph):
+                run(ph, ph + 1)
+                if ph < nph - 1:
+                    sync(module._stats_view(shape, ws, ph, False))
+        ctx.shape, ctx.module = shape, module
+        ctx.save_for_backward(x, ws, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _hip.lib()
+        x, ws, *params = ctx.saved_tensors
+        shape, module = ctx.shape, ctx.module
+        dout = dout.contiguous()
+        wb = torch.empty(L.ocean_dcnn_bwd_workspace(ctypes.byref(shape)), device=x.device, dtype=torch.float32)
+        is_stat = module._stat_slots()
+        grads = [None if is_stat[i] else torch.zeros_like(p) for i, p in enumerate(params)]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ptab = _hip.ptr_table(params, "dcnn param")
+        gtab = _hip.ptr_table(grads, "dcnn grad")
+        nph = L.ocean_dcnn_num_phases(ctypes.byref(shape))
+        sync = module.stats_all_reduce if shape.training else None
+
+        def run(lo, hi):
+            _hip.check(L.ocean_dcnn_bwd(ctypes.byref(shape), _hip.dev_ptr(x), ptab, _hip.dev_ptr(ws), _hip.dev_ptr(wb),
+                                        wb.numel(), _hip.dev_ptr(dout, "grad_output"), gtab, _hip.dev_ptr(dx),
+                                        lo, hi, _hip.stream()), "ocean_dcnn_bwd")
+        if sync is None:
+            run(0, nph)
+        else:
+            for ph in range(nph):
+                run(ph, ph + 1)
+                if ph < nph - 1:
+                    sync(module._stats_view(shape, wb, ph, True))
+        out = [dx, None]
+        for i, g in enumerate(grads):
+            out.append(g if (g is not None and ctx.needs_input_grad[2 + i]) else None)
+        return tuple(out)
+
+
+class DilatedCNN(nn.Module):
+    """DilatedCNN(input_dim, channels, kernel_size, dilation_rates, dropout,
+    activation, output_dim, global_pooling): [B,T,F] -> [B,output_dim]
+    (dilated_cnn.py:108-116, 195-241)."""
+
+    def __init__(self, input_dim: int, channels: Optional[List[int]] = None, kernel_size: int = 3,
+                 dilation_rates: Optional[List[int]] = None, dropout: float = 0.1, activation: str = "relu",
+                 output_dim: Optional[int] = None, global_pooling: str = "mean"):
+        super().__init__()
+        channels = [64, 128, 256, 512] if channels is None else list(channels)
+        dilation_rates = [1, 2, 4, 8] if dilation_rates is None else list(dilation_rates)
+        if len(channels) != len(dilation_rates):
+            raise ValueError("Length of channels and dilation_rates must match")
+        if len(channels) > _hip.MAX_CONV_LAYERS:
+            raise ValueError(f"at most {_hip.MAX_CONV_LAYERS} dilated blocks are supported")
+        self.input_dim, self.channels, self.dilation_rates = input_dim, channels, dilation_rates
+        self.kernel_size, self.global_pooling, self.activation_name = kernel_size, global_pooling, activation
+        self.dropout_p = float(dropout)
+
+        self.input_projection = nn.Linear(input_dim, channels[0])
+        self.conv_layers = nn.ModuleList(
+            DilatedConvBlock(c, c, kernel_size, d, dropout, activation) for c, d in zip(channels, dilation_rates))
+        self.transition_layers = nn.ModuleList(
+            nn.Sequential(nn.Conv1d(channels[i], channels[i + 1], kernel_size=1, bias=False),
+                          nn.BatchNorm1d(channels[i + 1]), nn.ReLU(inplace=True), nn.Dropout(dropout))
+            for i in range(len(channels) - 1))
+        if global_pooling == "attention":
+            self.attention_pooling = nn.Sequential(nn.Linear(channels[-1], channels[-1] // 4), nn.ReLU(),
+                                                   nn.Linear(channels[-1] // 4, 1), nn.Softmax(dim=-1))
+        self.output_dim = output_dim if output_dim is not None else channels[-1]
+        self.output_projection = nn.Linear(channels[-1], self.output_dim)
+
+        # data-parallel hook: callable(all-reduce) applied to each fp64 BatchNorm
+        # statistics block, and the global number of rows behind those statistics
+        self.stats_all_reduce: Optional[Callable[[torch.Tensor], None]] = None
+        self.stats_world_size: int = 1
+
+    # ------------------------------------------------------------------ plumbing
+    def _bn_modules(self):
+        for blk in self.conv_layers:
+            yield blk.batch_norm
+        for tr in self.transition_layers:
+            yield tr[1]
+
+    def _param_list(self):
+        ps = [self.input_projection.weight, self.input_projection.bias]
+        for blk in self.conv_layers:
+            bn = blk.batch_norm
+            ps += [blk.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        for tr in self.transition_layers:
+            ps += [tr[0].weight, tr[1].weight, tr[1].bias, tr[1].running_mean, tr[1].running_var]
+        ps += [self.output_projection.weight, self.output_projection.bias]
+        return ps
+
+    def _stat_slots(self):
+        n = len(self.channels)
+        slots = [False, False]
+        for _ in range(2 * n - 1):
+            slots += [False, False, False, True, True]
+        return slots + [False, False]
+
+    def _shape(self, x: torch.Tensor) -> _hip.DcnnShape:
+        s = _hip.DcnnShape()
+        s.B, s.T, s.F = x.shape
+        s.L = len(self.channels)
+        for i, (c, d) in enumerate(zip(self.channels, self.dilation_rates)):
+            s.channels[i], s.dilations[i] = c, d
+        s.kernel_size, s.out_dim = self.kernel_size, self.output_dim
+        s.training = int(self.training)
+        bn0 = self.conv_layers[0].batch_norm
+        s.eps, s.momentum = bn0.eps, (bn0.momentum if bn0.momentum is not None else 0.1)
+        s.bn_count = x.shape[0] * x.shape[1] * (self.stats_world_size if self.stats_all_reduce else 1)
+        p = self.conv_layers[0].dropout.p if self.training else 0.0
+        s.dropout = p
+        s.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+        return s
+
+    @staticmethod
+    def _stats_view(shape, ws, phase, backward):
+        off, n = ctypes.c_size_t(0), ctypes.c_int(0)
+        _hip.check(_hip.lib().ocean_dcnn_stats_block(ctypes.byref(shape), phase, int(backward),
+                                                     ctypes.byref(off), ctypes.byref(n)), "ocean_dcnn_stats_block")
+        return ws[off.value: off.value + 2 * n.value].view(torch.float64)
+
+    # ------------------------------------------------------------------ API
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 3 or x.shape[2] != self.input_dim:
+            raise ValueError(f"expected metrics of shape (batch, seq_len, {self.input_dim}), got {tuple(x.shape)}")
+        if self.global_pooling not in ("mean", "max", "attention"):
+            raise ValueError(f"Unsupported global pooling: {self.global_pooling}")
+        if self.global_pooling != "mean" or self.activation_name != "relu" or self.kernel_size % 2 == 0 \
+                or any(not b.use_residual for b in self.conv_layers):
+            raise NotImplementedError("the HIP path implements relu activation, mean pooling, odd kernel sizes")
+        bsz, seq = x.shape[0], x.shape[1]
+        if self.training and bsz * seq * (self.stats_world_size if self.stats_all_reduce else 1) == 1:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size "
+                             f"{torch.Size([bsz, self.channels[0], seq])}")
+        x = x.contiguous().float()
+        out = _DcnnFunction.apply(x, self, *self._param_list())
+        if self.training:
+            with torch.no_grad():
+                for bn in self._bn_modules():
+                    bn.num_batches_tracked += 1
+        return out
+
+    def compute_receptive_field(self) -> int:
+        return 1 + sum((self.kernel_size - 1) * d for d in self.dilation_rates)
+
+    def get_model_info(self) -> dict:
+        total = sum(p.numel() for p in self.parameters())
+        return {"model_type": "DilatedCNN", "input_dim": self.input_dim, "channels": self.channels,
+                "dilation_rates": self.dilation_rates, "num_layers": len(self.conv_layers), "receptive_field": self.compute_receptive_field(),
+                "global_pooling": self.global_pooling, "total_parameters": total,
+                "trainable_parameters": sum(p.numel() for p in self.parameters() if p.requires_grad)}
