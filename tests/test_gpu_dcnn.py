@@ -91,10 +91,14 @@ def test_against_oracle_random(B, T_, ch, dil, k):
     xg = x.cuda().requires_grad_(True)
     y = m(xg)
     (y * gw.cuda()).sum().backward()
+    # two values per channel make BatchNorm's x_hat = +-1 with var ~ 0: the
+    # backward is a difference of nearly equal terms scaled by 1/std, so fp32
+    # evaluation-order noise is amplified ~10x there
+    gtol = 1e-2 if B * T_ <= 2 else 1e-3
     close(y, yr, 1e-4)
-    close(xg.grad, xr.grad, 1e-3)
+    close(xg.grad, xr.grad, gtol)
     for name, p in m.named_parameters():
-        close(p.grad, ref_sd[name].grad, 1e-3)
+        close(p.grad, ref_sd[name].grad, gtol)
     for name, v in m.state_dict().items():
         if "running" in name:
             close(v, ref_sd[name], 1e-5)

@@ -64,7 +64,8 @@ def test_strided_output_and_unaligned_pointers():
     a, w = _rand(M, K, seed=1), _rand(N, K, seed=2)
     big = torch.zeros(M, 64, device="cuda")
     view = big[:, 8:]                      # write into columns 8..27 of a wider matrix
-    st = _hip.lib().ocean_gemm_f32(_hip.dev_ptr(a.cuda().contiguous()), K, _hip.dev_ptr(w.cuda().contiguous()), K,
+    ad, wd = a.cuda(), w.cuda()            # keep the device operands alive across the raw calls
+    st = _hip.lib().ocean_gemm_f32(_hip.dev_ptr(ad), K, _hip.dev_ptr(wd), K,
                                    view.data_ptr(), 64, M, N, K, 0, 0, None, None, 0, 0, _hip.stream())
     assert st == 0
     torch.cuda.synchronize()
@@ -74,7 +75,7 @@ def test_strided_output_and_unaligned_pointers():
     ab = torch.zeros(M * K + 1, device="cuda")
     ab[1:] = a.flatten().cuda()
     out = torch.empty(M, N, device="cuda")
-    st = _hip.lib().ocean_gemm_f32(ab.data_ptr() + 4, K, _hip.dev_ptr(w.cuda().contiguous()), K, _hip.dev_ptr(out), N,
+    st = _hip.lib().ocean_gemm_f32(ab.data_ptr() + 4, K, _hip.dev_ptr(wd), K, _hip.dev_ptr(out), N,
                                    M, N, K, 0, 0, None, None, 0, 0, _hip.stream())
     assert st == 0
     _close(out, a.double() @ w.double().t())
