@@ -95,6 +95,40 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
                    const float* dout /* [B,out_dim] */, float* const* grads,
                    float* dx /* [B,T,F] or NULL */, int phase_lo, int phase_hi, void* stream);
 
+/* ------------------------------------------------------------------ GraphNeuralNetwork (GAT)
+ * Replaces GraphNeuralNetwork.forward with conv_type='gat', pooling='mean',
+ * batch_norm=False (ocean/models/components/graph_neural_network.py:236-302),
+ * the torch_geometric GATConv / global_mean_pool it calls (:187-193, :258, :290)
+ * and the O(B^2) batched-graph construction of ocean_model.py:155-171, plus
+ * their backward.  One graph, R replicas: node tensors are [R*N, .].
+ *
+ * graph[] = { rowptr_in[N+1], src_in[E], rowptr_out[N+1], dst_out[E], eid_out[E] }
+ * device int32 arrays: incoming edges grouped by target (self loops already
+ * removed and re-added once per node), outgoing edges grouped by source, and
+ * for each outgoing edge its position in the by-target order.
+ */
+typedef struct {
+  int N, R;                 /* nodes per graph, replicas computed (1 when every replica is identical) */
+  int G, D, H;              /* node-feature width, hidden width (= H * per-head width), heads          */
+  int layers;               /* GAT layers; all concatenate heads except the last, which averages them  */
+  int E;                    /* edges in the CSRs, self loops included                                  */
+  int pool_n;               /* nodes per mean-pooled group (0 = N: one output row per replica)         */
+  int training;
+  float dropout;            /* feature and attention dropout p (graph_neural_network.py:191,218)       */
+  float negative_slope;     /* LeakyReLU slope of GATConv (0.2)                                        */
+  uint64_t seed;
+} ocean_gnn_shape;
+
+/* params: [0] input_projection.weight [D,G] [1] .bias [D]; per layer l: lin.weight [D,D], att_src [D],
+ * att_dst [D], bias [D or D/H]; then output_projection.weight [D, D/H], .bias [D].  grads: same order. */
+size_t ocean_gnn_fwd_workspace(const ocean_gnn_shape* s);
+size_t ocean_gnn_bwd_workspace(const ocean_gnn_shape* s);
+int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features /* [N,G] */, const int* const* graph,
+                  float* const* params, float* ws, size_t ws_floats, float* out /* [R*N/pool_n, D] */, void* stream);
+int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const int* const* graph,
+                  float* const* params, float* ws_fwd, float* ws_bwd, size_t ws_bwd_floats,
+                  const float* dout /* [R*N/pool_n, D] */, float* const* grads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

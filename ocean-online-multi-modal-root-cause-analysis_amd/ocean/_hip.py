@@ -33,6 +33,12 @@ class DcnnShape(ctypes.Structure):
                 ("dropout", c_float), ("seed", c_uint64)]
 
 
+class GnnShape(ctypes.Structure):
+    _fields_ = [("N", c_int), ("R", c_int), ("G", c_int), ("D", c_int), ("H", c_int), ("layers", c_int),
+                ("E", c_int), ("pool_n", c_int), ("training", c_int), ("dropout", c_float),
+                ("negative_slope", c_float), ("seed", c_uint64)]
+
+
 def _declare(lib) -> None:
     fp = POINTER(c_float)
     lib.ocean_abi_version.restype = c_int
@@ -57,6 +63,19 @@ def _declare(lib) -> None:
                                    POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p]
 
 
+def _declare_gnn(lib) -> None:
+    gp = POINTER(GnnShape)
+    lib.ocean_gnn_fwd_workspace.restype = c_size_t
+    lib.ocean_gnn_fwd_workspace.argtypes = [gp]
+    lib.ocean_gnn_bwd_workspace.restype = c_size_t
+    lib.ocean_gnn_bwd_workspace.argtypes = [gp]
+    lib.ocean_gnn_fwd.restype = c_int
+    lib.ocean_gnn_fwd.argtypes = [gp, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_size_t, c_void_p, c_void_p]
+    lib.ocean_gnn_bwd.restype = c_int
+    lib.ocean_gnn_bwd.argtypes = [gp, c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_size_t,
+                                  c_void_p, POINTER(c_void_p), c_void_p]
+
+
 def lib():
     """The loaded library; raises (never falls back) when it is absent."""
     global _lib
@@ -67,6 +86,7 @@ def lib():
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
         _lib = ctypes.CDLL(_LIB_PATH)
         _declare(_lib)
+        _declare_gnn(_lib)
     return _lib
 
 
