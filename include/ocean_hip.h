@@ -129,6 +129,115 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
                   float* const* params, float* ws_fwd, float* ws_bwd, size_t ws_bwd_floats,
                   const float* dout /* [R*N/pool_n, D] */, float* const* grads, void* stream);
 
+/* ------------------------------------------------------------------ MultiFactorAttention
+ * Replaces MultiFactorAttention.forward with fusion_strategy='concatenate'
+ * (ocean/models/components/multi_factor_attention.py:312-440) and backward.
+ * params (37 pointers): temporal/spatial/log_projection (w,b) x3;
+ * {temporal,spatial,log}_self_attention (w_v.w, w_v.b, w_o.w, w_o.b) x3;
+ * layer_norms temporal/spatial/log/output (weight,bias) x4; modality_weights[3];
+ * feature_attention.0 (w,b), feature_attention.2 (w,b); fusion_layer (w,b);
+ * output_projection.0 (w,b), output_projection.3 (w,b).  grads: same order. */
+typedef struct {
+  int B, td, sd, ld;        /* rows; widths of the temporal / spatial / log inputs */
+  int W, heads;             /* attention_dim, num_heads                              */
+  int training;
+  float dropout, eps;       /* attention_dropout; LayerNorm eps (1e-5)               */
+  uint64_t seed;
+} ocean_mfa_shape;
+size_t ocean_mfa_fwd_workspace(const ocean_mfa_shape* s);
+size_t ocean_mfa_bwd_workspace(const ocean_mfa_shape* s);
+int ocean_mfa_fwd(const ocean_mfa_shape* s, const float* temporal, const float* spatial, const float* logs,
+                  float* const* params, float* ws, size_t ws_floats, float* out /* [B,W] */, void* stream);
+int ocean_mfa_bwd(const ocean_mfa_shape* s, const float* temporal, const float* spatial, const float* logs,
+                  float* const* params, float* ws_fwd, float* ws_bwd, size_t ws_bwd_floats, const float* dout,
+                  float* const* grads, float* d_temporal, float* d_spatial, float* d_logs /* each may be NULL */,
+                  void* stream);
+
+/* ------------------------------------------------------------------ GraphFusionModule
+ * Replaces GraphFusionModule.forward with fusion_strategy='attention'
+ * (ocean/models/components/graph_fusion.py:388-473) including
+ * nn.MultiheadAttention over the 3 modality tokens (:353-358) and, when
+ * `contrastive`, the three ProjectionHeads (:77-92); and backward.
+ * params (34 pointers): {temporal,spatial,log}_processor (0.weight, 0.bias, 3.weight, 3.bias) x3;
+ * attention_fusion in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias; attention_norm (w,b);
+ * output_projection.0 (w,b), .3 (w,b); projection_heads.{temporal,spatial,log}.projection (0.w,0.b,3.w,3.b) x3. */
+typedef struct {
+  int B, td, sd, ld;
+  int E, Pd, heads;         /* fusion_dim, projection_dim, attention heads (8) */
+  int training, contrastive;
+  float dropout, eps;
+  uint64_t seed;
+} ocean_fusion_shape;
+size_t ocean_fusion_fwd_workspace(const ocean_fusion_shape* s);
+size_t ocean_fusion_bwd_workspace(const ocean_fusion_shape* s);
+int ocean_fusion_fwd(const ocean_fusion_shape* s, const float* temporal, const float* spatial, const float* logs,
+                     float* const* params, float* ws, size_t ws_floats, float* fused /* [B,E] */,
+                     float* processed /* [B,3,E] */, float* projections /* [3,B,Pd] or NULL */, void* stream);
+int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* temporal, const float* spatial, const float* logs,
+                     float* const* params, float* ws_fwd, const float* processed, const float* projections,
+                     float* ws_bwd, size_t ws_bwd_floats, const float* d_fused /* or NULL */,
+                     const float* d_processed /* or NULL */, const float* d_projections /* or NULL */,
+                     float* const* grads, float* d_temporal, float* d_spatial, float* d_logs, void* stream);
+
+/* ------------------------------------------------------------------ InfoNCE
+ * Replaces InfoNCELoss.forward (graph_fusion.py:112-162) and backward.
+ * K > 0: memory-bank branch, logits = [a.p, a.n_1 .. a.n_K]/tau, label 0 (Bp == B).
+ * K == 0: in-batch branch, logits = a . p^T / tau over Bp positives (all ranks'
+ * rows when data-parallel), label of row b = label_offset + b.
+ * *loss is ACCUMULATED (+= mean over mean_rows, 0 -> B). */
+typedef struct {
+  int B, Bp, P, K;
+  int label_offset, mean_rows;
+  float tau;
+} ocean_infonce_shape;
+size_t ocean_infonce_workspace(const ocean_infonce_shape* s);
+size_t ocean_infonce_bwd_workspace(const ocean_infonce_shape* s);
+int ocean_infonce_fwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, const float* negatives,
+                      float* ws, size_t ws_floats, float* loss, void* stream);
+int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, float* ws, float* ws_bwd,
+                      size_t ws_bwd_floats, const float* dloss /* device scalar or NULL (=1) */, float* d_anchor /* [B,P] */,
+                      float* d_positive /* [Bp,P] */, void* stream);
+
+/* ------------------------------------------------------------------ prediction head + sigmoid
+ * Replaces prediction_head + output_activation (ocean/models/ocean_model.py:112-125, 205-206).
+ * params: 0.weight [h1,E], 0.bias, 3.weight [h2,h1], 3.bias, 6.weight [S,h2], 6.bias. */
+typedef struct {
+  int B, E, h1, h2, S;
+  int training;
+  float dropout;            /* 0.1 hard-coded in the reference (ocean_model.py:117,120) */
+  uint64_t seed;
+} ocean_head_shape;
+size_t ocean_head_workspace(const ocean_head_shape* s);
+size_t ocean_head_bwd_workspace(const ocean_head_shape* s);
+int ocean_head_fwd(const ocean_head_shape* s, const float* x, float* const* params, float* ws, size_t ws_floats,
+                   float* logits, float* probs, void* stream);
+int ocean_head_bwd(const ocean_head_shape* s, const float* x, float* const* params, float* ws_fwd, float* ws_bwd,
+                   size_t ws_bwd_floats, const float* probs, const float* d_logits /* or NULL */,
+                   const float* d_probs /* or NULL */, float* const* grads, float* dx /* or NULL */, void* stream);
+
+/* F.binary_cross_entropy(probs, targets, reduction='mean') (ocean_model.py:249-253; trainer.py:79).
+ * *loss is ACCUMULATED; mean over mean_n elements (0 -> n). */
+int ocean_bce_fwd(const float* probs, const float* targets, long n, long mean_n, float* loss, void* stream);
+int ocean_bce_bwd(const float* probs, const float* targets, const float* dloss /* device scalar or NULL */,
+                  long n, long mean_n, float* d_probs, void* stream);
+
+/* ------------------------------------------------------------------ clip + Adam
+ * Replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step as used at
+ * ocean/models/training/online_learner.py:325-335, 402-412 (Adam constructed
+ * at :256-261: coupled L2 weight decay, no amsgrad).  `table` is a DEVICE array
+ * with one row per chunk of consecutive elements of one tensor. */
+typedef struct {
+  uint64_t param, grad, exp_avg, exp_avg_sq;   /* device addresses of fp32 data */
+  int64_t n;                                    /* elements in this chunk        */
+} ocean_adam_chunk;
+/* *sqnorm (device fp64, pre-zeroed) += sum of squares of every gradient in the table */
+int ocean_grad_sqnorm(const ocean_adam_chunk* table, int n_chunks, double* sqnorm, void* stream);
+/* g *= min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) when max_norm > 0 and sqnorm != NULL; then the Adam update
+ * with bias corrections for `step` (1-based).  write_clipped: store the clipped gradient back. */
+int ocean_clip_adam_step(const ocean_adam_chunk* table, int n_chunks, const double* sqnorm, float max_norm,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                         int write_clipped, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,300 @@
+// InfoNCE (memory-bank and in-batch branches), prediction head + sigmoid, and
+// binary cross-entropy: forward and backward.
+//
+// InfoNCE (graph_fusion.py:112-162): both inputs are L2-normalised again, the
+// similarity matrix a_hat . x_hat^T is one fp32-MFMA GEMM ([B,K] with K = 16
+// bank rows, or [B, B_global] for in-batch negatives), and a wave-per-row
+// kernel takes the temperature-scaled log-sum-exp.  Backward turns the saved
+// similarities into (softmax - onehot) * dloss / (B * tau) in place and feeds
+// two GEMMs (d a_hat = dL . x_hat, d x_hat = dL^T . a_hat).
+#include "../../include/ocean_hip.h"
+#include "ops.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+constexpr int kWaves = 4;
+
+// sim[b, 0] = a_hat[b] . p_hat[b]   (bank branch keeps the positive in column 0)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ p, float* __restrict__ out,
+                                                     int ldo, int B, int P) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float d = 0.f;
+  for (int c = lane; c < P; c += 64) d += a[(long)b * P + c] * p[(long)b * P + c];
+  d = wave_sum(d);
+  if (lane == 0) out[(long)b * ldo] = d;
+}
+
+// loss += sum_b (lse_b - sim[b,label_b]/tau) * inv_rows;  lse saved per row
+__global__ __launch_bounds__(256) void nce_rows_fwd_kernel(const float* __restrict__ sim, int ld, int B, int K, int label0, int label_step,
+                                                           float inv_tau, float inv_rows, float* __restrict__ lse_out,
+                                                           float* __restrict__ loss) {
+  __shared__ float red[kWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x * kWaves + wave;
+  float contrib = 0.f;
+  if (b < B) {
+    const float* r = sim + (long)b * ld;
+    float m = -INFINITY;
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, r[k] * inv_tau);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += __expf(r[k] * inv_tau - m);
+    s = wave_sum(s);
+    const float lse = m + __logf(s);
+    const int label = label0 + label_step * b;
+    contrib = (lse - r[label] * inv_tau) * inv_rows;
+    if (lane == 0) lse_out[b] = lse;
+  }
+  if (lane == 0) red[wave] = contrib;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+}
+
+// sim[b,k] <- (softmax_k(sim/tau) - [k == label_b]) * dloss * inv_rows * inv_tau
+__global__ __launch_bounds__(256) void nce_rows_bwd_kernel(float* __restrict__ sim, int ld, int B, int K, int label0, int label_step,
+                                                           float inv_tau, float inv_rows, const float* __restrict__ lse,
+                                                           const float* __restrict__ dloss) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float* r = sim + (long)b * ld;
+  const float g = (dloss ? dloss[0] : 1.0f) * inv_rows * inv_tau;
+  const float l = lse[b];
+  const int label = label0 + label_step * b;
+  for (int k = lane; k < K; k += 64) r[k] = (__expf(r[k] * inv_tau - l) - (k == label ? 1.f : 0.f)) * g;
+}
+
+// out[b,:] (+)= col0[b] * src[b,:]
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ col0, int ld0, const float* __restrict__ src,
+                                                       float* __restrict__ out, int B, int P, int accumulate) {
+  const long n = (long)B * P;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / P;
+    const float v = col0[b * ld0] * src[i];
+    if (accumulate) out[i] += v; else out[i] = v;
+  }
+}
+
+__global__ void sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = 1.0f / (1.0f + __expf(-x[i]));
+}
+// dlogits = dlogits_in + dprobs * p * (1 - p)
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dlogits_in, const float* __restrict__ dprobs, const float* __restrict__ p,
+                                   float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = dlogits_in ? dlogits_in[i] : 0.f;
+    if (dprobs) v += dprobs[i] * p[i] * (1.0f - p[i]);
+    out[i] = v;
+  }
+}
+
+// F.binary_cross_entropy(p, y, 'mean'): log terms clamped at -100
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y, long n, float inv_n,
+                                                      float* __restrict__ loss) {
+  __shared__ float red[kWaves];
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float lp = fmaxf(logf(p[i]), -100.f), lq = fmaxf(log1pf(-p[i]), -100.f);
+    s -= y[i] * lp + (1.0f - y[i]) * lq;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+// dp = dloss * (p - y) / max(p (1-p), 1e-12) / n
+__global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y, const float* __restrict__ dloss, long n,
+                               float inv_n, float* __restrict__ dp) {
+  const float g = (dloss ? dloss[0] : 1.0f) * inv_n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dp[i] = g * (p[i] - y[i]) / fmaxf(p[i] * (1.0f - p[i]), 1e-12f);
+}
+
+inline int egrid(long n) {
+  long g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+inline size_t al4(size_t x) { return (x + 3) & ~size_t(3); }
+
+struct NcePlan { size_t ah, ph, nh, na, np, nn, sim, lse, total; int ldsim; };
+int nce_plan(const ocean_infonce_shape* s, NcePlan* p) {
+  if (!s) return OCEAN_ERR_NULL;
+  if (s->B <= 0 || s->Bp <= 0 || s->P <= 0 || s->K < 0 || !(s->tau > 0.f)) return OCEAN_ERR_BAD_SHAPE;
+  if (s->K == 0 && (s->label_offset < 0 || s->label_offset + s->B > s->Bp)) return OCEAN_ERR_BAD_SHAPE;
+  if (s->K > 0 && s->Bp != s->B) return OCEAN_ERR_BAD_SHAPE;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o = al4(o + n); return r; };
+  p->ah = take((size_t)s->B * s->P); p->ph = take((size_t)s->Bp * s->P); p->nh = take((size_t)s->K * s->P);
+  p->na = take(s->B); p->np = take(s->Bp); p->nn = take(s->K);
+  p->ldsim = s->K > 0 ? al4(1 + s->K) + 4 : s->Bp;       // bank: column 0 = positive, negatives start at column 4 (16-byte aligned)
+  p->sim = take((size_t)s->B * p->ldsim); p->lse = take(s->B);
+  p->total = o;
+  return OCEAN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ocean_infonce_workspace(const ocean_infonce_shape* s) { NcePlan p; return nce_plan(s, &p) == OCEAN_OK ? p.total : 0; }
+size_t ocean_infonce_bwd_workspace(const ocean_infonce_shape* s) {
+  return s ? al4((size_t)s->B * s->P) + al4((size_t)s->Bp * s->P) : 0;
+}
+
+int ocean_infonce_fwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, const float* negatives,
+                      float* ws, size_t ws_floats, float* loss, void* stream) {
+  NcePlan pl;
+  OCEAN_TRY(nce_plan(s, &pl));
+  if (!anchor || !positive || !ws || !loss || (s->K > 0 && !negatives)) return OCEAN_ERR_NULL;
+  if (ws_floats < pl.total) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, P = s->P, K = s->K;
+  const float inv_tau = 1.0f / s->tau, inv_rows = 1.0f / (float)(s->mean_rows > 0 ? s->mean_rows : B);
+  OCEAN_TRY(l2norm_fwd(anchor, P, ws + pl.ah, P, ws + pl.na, B, P, 1e-12f, st));
+  OCEAN_TRY(l2norm_fwd(positive, P, ws + pl.ph, P, ws + pl.np, s->Bp, P, 1e-12f, st));
+  if (K > 0) {
+    OCEAN_TRY(l2norm_fwd(negatives, P, ws + pl.nh, P, ws + pl.nn, K, P, 1e-12f, st));
+    // similarity layout per row: [pos, (3 unused), neg_0 .. neg_{K-1}]; the row kernels see columns {0} U [4, 4+K)
+    // by compacting: write pos at column 3 so that columns 3 .. 3+K are contiguous
+    hipLaunchKernelGGL(rowdot_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.ah, ws + pl.ph, ws + pl.sim + 3, pl.ldsim, B, P);
+    OCEAN_LAUNCH_CHECK();
+    GemmP g = gemm_defaults();
+    g.A = ws + pl.ah; g.lda = P; g.B = ws + pl.nh; g.ldb = P; g.C = ws + pl.sim + 4; g.ldc = pl.ldsim; g.M = B; g.N = K; g.K = P;
+    OCEAN_TRY(ocean_launch_gemm(g, st));
+    hipLaunchKernelGGL(nce_rows_fwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.sim + 3, pl.ldsim, B, K + 1, 0, 0, inv_tau,
+                       inv_rows, ws + pl.lse, loss);
+  } else {
+    GemmP g = gemm_defaults();
+    g.A = ws + pl.ah; g.lda = P; g.B = ws + pl.ph; g.ldb = P; g.C = ws + pl.sim; g.ldc = pl.ldsim; g.M = B; g.N = s->Bp; g.K = P;
+    OCEAN_TRY(ocean_launch_gemm(g, st));
+    hipLaunchKernelGGL(nce_rows_fwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.sim, pl.ldsim, B, s->Bp, s->label_offset, 1,
+                       inv_tau, inv_rows, ws + pl.lse, loss);
+  }
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, float* ws, float* wb,
+                      size_t wb_floats, const float* dloss, float* d_anchor, float* d_positive, void* stream) {
+  NcePlan pl;
+  OCEAN_TRY(nce_plan(s, &pl));
+  if (!ws || !wb || !d_anchor || !d_positive) return OCEAN_ERR_NULL;
+  if (wb_floats < ocean_infonce_bwd_workspace(s)) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, P = s->P, K = s->K, Bp = s->Bp;
+  const float inv_tau = 1.0f / s->tau, inv_rows = 1.0f / (float)(s->mean_rows > 0 ? s->mean_rows : B);
+  float* dah = wb; float* dph = wb + al4((size_t)B * P);
+  if (K > 0) {
+    float* sim = ws + pl.sim + 3;
+    hipLaunchKernelGGL(nce_rows_bwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, sim, pl.ldsim, B, K + 1, 0, 0, inv_tau, inv_rows,
+                       ws + pl.lse, dloss);
+    OCEAN_LAUNCH_CHECK();
+    // d a_hat = dL[:,0] * p_hat + dL[:,1:] . n_hat ;  d p_hat = dL[:,0] * a_hat
+    OCEAN_TRY(linear_bwd_data(sim + 1, pl.ldsim, ws + pl.nh, dah, P, B, K, P, 0, st));
+    hipLaunchKernelGGL(rowscale_kernel, dim3(egrid((long)B * P)), dim3(256), 0, st, sim, pl.ldsim, ws + pl.ph, dah, B, P, 1);
+    OCEAN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rowscale_kernel, dim3(egrid((long)B * P)), dim3(256), 0, st, sim, pl.ldsim, ws + pl.ah, dph, B, P, 0);
+    OCEAN_LAUNCH_CHECK();
+  } else {
+    float* sim = ws + pl.sim;
+    hipLaunchKernelGGL(nce_rows_bwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, sim, pl.ldsim, B, Bp, s->label_offset, 1, inv_tau,
+                       inv_rows, ws + pl.lse, dloss);
+    OCEAN_LAUNCH_CHECK();
+    OCEAN_TRY(linear_bwd_data(sim, pl.ldsim, ws + pl.ph, dah, P, B, Bp, P, 0, st));      // [B,Bp] . [Bp,P]
+    OCEAN_TRY(zero_f32(dph, (size_t)Bp * P, st));
+    OCEAN_TRY(linear_bwd_weight(sim, pl.ldsim, ws + pl.ah, P, dph, B, Bp, P, st));       // [B,Bp]^T . [B,P]
+  }
+  OCEAN_TRY(l2norm_bwd(dah, P, ws + pl.ah, P, ws + pl.na, d_anchor, P, B, P, 1e-12f, st));
+  OCEAN_TRY(l2norm_bwd(dph, P, ws + pl.ph, P, ws + pl.np, d_positive, P, Bp, P, 1e-12f, st));
+  return OCEAN_OK;
+}
+
+// ---------------------------------------------------------------- prediction head
+size_t ocean_head_workspace(const ocean_head_shape* s) {
+  return s ? al4((size_t)s->B * s->h1) + al4((size_t)s->B * s->h2) : 0;
+}
+size_t ocean_head_bwd_workspace(const ocean_head_shape* s) {
+  return s ? al4((size_t)s->B * s->S) + al4((size_t)s->B * s->h1) + al4((size_t)s->B * s->h2) : 0;
+}
+
+static DropoutP head_site(const ocean_head_shape* s, int id) {
+  DropoutP d;
+  d.p = s->training ? s->dropout : 0.f;
+  d.seed = s->seed + 0xC2B2AE3D27D4EB4Full * (uint64_t)(id + 1);
+  return d;
+}
+
+int ocean_head_fwd(const ocean_head_shape* s, const float* x, float* const* P_, float* ws, size_t ws_floats, float* logits,
+                   float* probs, void* stream) {
+  if (!s || !x || !P_ || !ws || !logits || !probs) return OCEAN_ERR_NULL;
+  if (s->B <= 0 || s->E <= 0 || s->h1 <= 0 || s->h2 <= 0 || s->S <= 0) return OCEAN_ERR_BAD_SHAPE;
+  if (ws_floats < ocean_head_workspace(s)) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* a1 = ws; float* a2 = ws + al4((size_t)s->B * s->h1);
+  OCEAN_TRY(linear_fwd(x, s->E, P_[0], P_[1], a1, s->h1, s->B, s->h1, s->E, 1, st));
+  OCEAN_TRY(dropout_inplace(a1, s->h1, s->B, s->h1, 1, head_site(s, 0), st));
+  OCEAN_TRY(linear_fwd(a1, s->h1, P_[2], P_[3], a2, s->h2, s->B, s->h2, s->h1, 1, st));
+  OCEAN_TRY(dropout_inplace(a2, s->h2, s->B, s->h2, 1, head_site(s, 1), st));
+  OCEAN_TRY(linear_fwd(a2, s->h2, P_[4], P_[5], logits, s->S, s->B, s->S, s->h2, 0, st));
+  hipLaunchKernelGGL(sigmoid_kernel, dim3(egrid((long)s->B * s->S)), dim3(256), 0, st, logits, probs, (long)s->B * s->S);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int ocean_head_bwd(const ocean_head_shape* s, const float* x, float* const* P_, float* ws, float* wb, size_t wb_floats,
+                   const float* probs, const float* dlogits, const float* dprobs, float* const* G_, float* dx, void* stream) {
+  if (!s || !x || !P_ || !ws || !wb || !probs || !G_) return OCEAN_ERR_NULL;
+  if (wb_floats < ocean_head_bwd_workspace(s)) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B;
+  const float* a1 = ws; const float* a2 = ws + al4((size_t)B * s->h1);
+  float* dl = wb; float* d1 = wb + al4((size_t)B * s->S); float* d2 = d1 + al4((size_t)B * s->h1);
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(egrid((long)B * s->S)), dim3(256), 0, st, dlogits, dprobs, probs, dl, (long)B * s->S);
+  OCEAN_LAUNCH_CHECK();
+  OCEAN_TRY(linear_bwd_weight(dl, s->S, a2, s->h2, G_[4], B, s->S, s->h2, st));
+  OCEAN_TRY(colsum_add(dl, s->S, B, s->S, G_[5], st));
+  OCEAN_TRY(linear_bwd_data(dl, s->S, P_[4], d2, s->h2, B, s->S, s->h2, 0, st));
+  OCEAN_TRY(dropout_inplace(d2, s->h2, B, s->h2, 1, head_site(s, 1), st));
+  OCEAN_TRY(relu_bwd_inplace(d2, s->h2, a2, s->h2, B, s->h2, st));
+  OCEAN_TRY(linear_bwd_weight(d2, s->h2, a1, s->h1, G_[2], B, s->h2, s->h1, st));
+  OCEAN_TRY(colsum_add(d2, s->h2, B, s->h2, G_[3], st));
+  OCEAN_TRY(linear_bwd_data(d2, s->h2, P_[2], d1, s->h1, B, s->h2, s->h1, 0, st));
+  OCEAN_TRY(dropout_inplace(d1, s->h1, B, s->h1, 1, head_site(s, 0), st));
+  OCEAN_TRY(relu_bwd_inplace(d1, s->h1, a1, s->h1, B, s->h1, st));
+  OCEAN_TRY(linear_bwd_weight(d1, s->h1, x, s->E, G_[0], B, s->h1, s->E, st));
+  OCEAN_TRY(colsum_add(d1, s->h1, B, s->h1, G_[1], st));
+  if (dx) OCEAN_TRY(linear_bwd_data(d1, s->h1, P_[0], dx, s->E, B, s->h1, s->E, 0, st));
+  return OCEAN_OK;
+}
+
+// ---------------------------------------------------------------- BCE
+int ocean_bce_fwd(const float* probs, const float* targets, long n, long mean_n, float* loss, void* stream) {
+  if (!probs || !targets || !loss) return OCEAN_ERR_NULL;
+  if (n <= 0) return OCEAN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(egrid(n) > 512 ? 512 : egrid(n)), dim3(256), 0, (hipStream_t)stream, probs, targets, n,
+                     1.0f / (float)(mean_n > 0 ? mean_n : n), loss);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+int ocean_bce_bwd(const float* probs, const float* targets, const float* dloss, long n, long mean_n, float* dprobs, void* stream) {
+  if (!probs || !targets || !dprobs) return OCEAN_ERR_NULL;
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, probs, targets, dloss, n,
+                     1.0f / (float)(mean_n > 0 ? mean_n : n), dprobs);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+// MultiFactorAttention forward / backward driver (multi_factor_attention.py:312-440).
+//
+// All projections are fp32-MFMA GEMMs on [B, .] (or stacked [3B, .]) matrices;
+// the glue between them is three small row kernels: the 2-key cross-modal
+// softmax over the three LayerNormed modality vectors, the sigmoid feature
+// gate, and LayerNorm (rowops).  The per-modality self-attention runs on a
+// length-1 sequence, so its softmax is identically 1 and the block reduces to
+// W_o(W_v x + b_v) + b_o with the reference's two dropouts (per-head on the
+// attention weight, then on the output); W_q / W_k never influence the result
+// and receive no gradient here (the reference gives them exact zeros).
+#include "../../include/ocean_hip.h"
+#include "ops.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int kWaves = 4;
+
+// Nn: [3][B][W] LayerNormed modality vectors (t, s, l).  G[m] = pi_m * (n_m + w1 k1 + w2 k2) with
+// (k1,k2) = (s,l) for t, (t,l) for s, (t,s) for l and (w1,w2) = softmax([n_m.k1, n_m.k2]/sqrt(W)).
+__global__ __launch_bounds__(256) void cross_fwd_kernel(const float* __restrict__ Nn, const float* __restrict__ mw,
+                                                        float* __restrict__ G, float* __restrict__ cw, int B, int W) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float* nt = Nn + (long)b * W;
+  const float* ns = Nn + ((long)B + b) * W;
+  const float* nl = Nn + (2L * B + b) * W;
+  float dts = 0.f, dtl = 0.f, dsl = 0.f;
+  for (int c = lane; c < W; c += 64) { const float t = nt[c], s = ns[c], l = nl[c]; dts += t * s; dtl += t * l; dsl += s * l; }
+  const float sc = 1.0f / sqrtf((float)W);
+  dts = wave_sum(dts) * sc; dtl = wave_sum(dtl) * sc; dsl = wave_sum(dsl) * sc;
+  auto sm2 = [](float a, float bb, float& w1, float& w2) { const float m = fmaxf(a, bb); const float ea = __expf(a - m), eb = __expf(bb - m); w1 = ea / (ea + eb); w2 = eb / (ea + eb); };
+  float wt1, wt2, ws1, ws2, wl1, wl2;
+  sm2(dts, dtl, wt1, wt2); sm2(dts, dsl, ws1, ws2); sm2(dtl, dsl, wl1, wl2);
+  const float m0 = mw[0], m1 = mw[1], m2 = mw[2], mm = fmaxf(m0, fmaxf(m1, m2));
+  const float e0 = __expf(m0 - mm), e1 = __expf(m1 - mm), e2 = __expf(m2 - mm), es = e0 + e1 + e2;
+  const float p0 = e0 / es, p1 = e1 / es, p2 = e2 / es;
+  for (int c = lane; c < W; c += 64) {
+    const float t = nt[c], s = ns[c], l = nl[c];
+    G[(long)b * W + c] = p0 * (t + wt1 * s + wt2 * l);
+    G[((long)B + b) * W + c] = p1 * (s + ws1 * t + ws2 * l);
+    G[(2L * B + b) * W + c] = p2 * (l + wl1 * t + wl2 * s);
+  }
+  if (lane == 0) { float* o = cw + (long)b * 6; o[0] = wt1; o[1] = wt2; o[2] = ws1; o[3] = ws2; o[4] = wl1; o[5] = wl2; }
+}
+
+__global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ Nn,
+                                                        const float* __restrict__ cw, const float* __restrict__ mw,
+                                                        float* __restrict__ dN, float* __restrict__ dpi, int B, int W) {
+  __shared__ float red[kWaves][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x * kWaves + wave;
+  float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
+  if (b < B) {
+    const float* nt = Nn + (long)b * W;
+    const float* ns = Nn + ((long)B + b) * W;
+    const float* nl = Nn + (2L * B + b) * W;
+    const float* gt = dG + (long)b * W;
+    const float* gs = dG + ((long)B + b) * W;
+    const float* gl = dG + (2L * B + b) * W;
+    const float* w = cw + (long)b * 6;
+    const float wt1 = w[0], wt2 = w[1], ws1 = w[2], ws2 = w[3], wl1 = w[4], wl2 = w[5];
+    const float m0 = mw[0], m1 = mw[1], m2 = mw[2], mm = fmaxf(m0, fmaxf(m1, m2));
+    const float e0 = __expf(m0 - mm), e1 = __expf(m1 - mm), e2 = __expf(m2 - mm), es = e0 + e1 + e2;
+    const float p0 = e0 / es, p1 = e1 / es, p2 = e2 / es;
+    // dots of de_m = pi_m * dg_m with each key, and dpi_m = dg_m . e_m
+    float at_s = 0.f, at_l = 0.f, as_t = 0.f, as_l = 0.f, al_t = 0.f, al_s = 0.f;
+    for (int c = lane; c < W; c += 64) {
+      const float t = nt[c], s = ns[c], l = nl[c], a = gt[c], bb = gs[c], cc = gl[c];
+      at_s += a * s; at_l += a * l; as_t += bb * t; as_l += bb * l; al_t += cc * t; al_s += cc * s;
+      dp0 += a * (t + wt1 * s + wt2 * l); dp1 += bb * (s + ws1 * t + ws2 * l); dp2 += cc * (l + wl1 * t + wl2 * s);
+    }
+    at_s = wave_sum(at_s) * p0; at_l = wave_sum(at_l) * p0; as_t = wave_sum(as_t) * p1; as_l = wave_sum(as_l) * p1;
+    al_t = wave_sum(al_t) * p2; al_s = wave_sum(al_s) * p2;
+    dp0 = wave_sum(dp0); dp1 = wave_sum(dp1); dp2 = wave_sum(dp2);
+    const float sc = 1.0f / sqrtf((float)W);
+    // softmax backward per modality: ds1 = w1*(dw1 - (w1 dw1 + w2 dw2)), scaled by 1/sqrt(W)
+    const float tt = wt1 * at_s + wt2 * at_l, dst1 = wt1 * (at_s - tt) * sc, dst2 = wt2 * (at_l - tt) * sc;
+    const float ss = ws1 * as_t + ws2 * as_l, dss1 = ws1 * (as_t - ss) * sc, dss2 = ws2 * (as_l - ss) * sc;
+    const float ll = wl1 * al_t + wl2 * al_s, dsl1 = wl1 * (al_t - ll) * sc, dsl2 = wl2 * (al_s - ll) * sc;
+    for (int c = lane; c < W; c += 64) {
+      const float t = nt[c], s = ns[c], l = nl[c];
+      const float a = gt[c] * p0, bb = gs[c] * p1, cc = gl[c] * p2;       // de_t, de_s, de_l
+      // t: query of its own block (keys s,l); key 1 of s's and l's blocks
+      const float dt = a + dst1 * s + dst2 * l + ws1 * bb + dss1 * s + wl1 * cc + dsl1 * l;
+      // s: query (keys t,l); key 1 of t's block, key 2 of l's block
+      const float ds = bb + dss1 * t + dss2 * l + wt1 * a + dst1 * t + wl2 * cc + dsl2 * l;
+      // l: query (keys t,s); key 2 of t's and s's blocks
+      const float dl = cc + dsl1 * t + dsl2 * s + wt2 * a + dst2 * t + ws2 * bb + dss2 * s;
+      dN[(long)b * W + c] = dt; dN[((long)B + b) * W + c] = ds; dN[(2L * B + b) * W + c] = dl;
+    }
+  }
+  if (lane == 0) { red[wave][0] = dp0; red[wave][1] = dp1; red[wave][2] = dp2; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int w2 = 0; w2 < kWaves; ++w2) s += red[w2][threadIdx.x];
+    unsafeAtomicAdd(dpi + threadIdx.x, s);
+  }
+}
+
+// d(modality_weights) through pi = softmax(mw)
+__global__ void modality_bwd_kernel(const float* __restrict__ dpi, const float* __restrict__ mw, float* __restrict__ dmw) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float m0 = mw[0], m1 = mw[1], m2 = mw[2], mm = fmaxf(m0, fmaxf(m1, m2));
+  const float e0 = __expf(m0 - mm), e1 = __expf(m1 - mm), e2 = __expf(m2 - mm), es = e0 + e1 + e2;
+  const float p[3] = {e0 / es, e1 / es, e2 / es};
+  const float dot = p[0] * dpi[0] + p[1] * dpi[1] + p[2] * dpi[2];
+  for (int i = 0; i < 3; ++i) dmw[i] += p[i] * (dpi[i] - dot);
+}
+
+// rows r in [0,3B): i = sigmoid(hid[r].w2 + b2);  cat[b, m*W + c] = G[r,c] * i   (r = m*B + b)
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ hid, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, const float* __restrict__ G,
+                                                       float* __restrict__ ig, float* __restrict__ cat, int B, int W, int Wh) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (r >= 3 * B) return;
+  float z = 0.f;
+  for (int k = lane; k < Wh; k += 64) z += hid[(long)r * Wh + k] * w2[k];
+  z = wave_sum(z) + b2[0];
+  const float i = 1.0f / (1.0f + __expf(-z));
+  const int m = r / B, b = r % B;
+  for (int c = lane; c < W; c += 64) cat[(long)b * 3 * W + m * W + c] = G[(long)r * W + c] * i;
+  if (lane == 0) ig[r] = i;
+}
+
+// dG = dcat * i;  dz = (dcat . G) * i(1-i);  dhid = dz * w2 where hid > 0
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dcat, const float* __restrict__ G,
+                                                       const float* __restrict__ ig, const float* __restrict__ hid,
+                                                       const float* __restrict__ w2, float* __restrict__ dG,
+                                                       float* __restrict__ dz, float* __restrict__ dhid, int B, int W, int Wh) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (r >= 3 * B) return;
+  const int m = r / B, b = r % B;
+  const float i = ig[r];
+  float d = 0.f;
+  for (int c = lane; c < W; c += 64) {
+    const float g = dcat[(long)b * 3 * W + m * W + c];
+    d += g * G[(long)r * W + c];
+    dG[(long)r * W + c] = g * i;
+  }
+  d = wave_sum(d) * i * (1.0f - i);
+  for (int k = lane; k < Wh; k += 64) dhid[(long)r * Wh + k] = hid[(long)r * Wh + k] > 0.f ? d * w2[k] : 0.f;
+  if (lane == 0) dz[r] = d;
+}
+
+struct MfaPlan {
+  int B, W, Wh;
+  size_t P, V, A, lnst, Nn, cw, G, Hd, ig, cat, F, O1, O2, lnso, fwd_total;
+  size_t d1, d2, dHd, dz, dcat, e1, e2, dpi, bwd_total;
+};
+inline size_t al4(size_t x) { return (x + 3) & ~size_t(3); }
+
+int make_plan(const ocean_mfa_shape* s, MfaPlan* p) {
+  if (!s) return OCEAN_ERR_NULL;
+  if (s->B <= 0 || s->td <= 0 || s->sd <= 0 || s->ld <= 0 || s->W <= 1 || s->heads <= 0 || s->W % s->heads != 0)
+    return OCEAN_ERR_BAD_SHAPE;
+  if (s->W > 1024) return OCEAN_ERR_UNSUPPORTED;
+  p->B = s->B; p->W = s->W; p->Wh = s->W / 2;
+  const size_t B = s->B, W = s->W, Wh = p->Wh;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o = al4(o + n); return r; };
+  p->P = take(3 * B * W); p->V = take(3 * B * W); p->A = take(3 * B * W); p->lnst = take(6 * B); p->Nn = take(3 * B * W);
+  p->cw = take(6 * B); p->G = take(3 * B * W); p->Hd = take(3 * B * Wh); p->ig = take(3 * B); p->cat = take(3 * B * W);
+  p->F = take(B * W); p->O1 = take(B * W); p->O2 = take(B * W); p->lnso = take(2 * B);
+  p->fwd_total = o;
+  o = 0;
+  p->d1 = take(3 * B * W); p->d2 = take(3 * B * W); p->dHd = take(3 * B * Wh); p->dz = take(3 * B); p->dcat = take(3 * B * W);
+  p->e1 = take(B * W); p->e2 = take(B * W); p->dpi = take(4);
+  p->bwd_total = o;
+  return OCEAN_OK;
+}
+
+DropoutP site(const ocean_mfa_shape* s, int id) {
+  DropoutP d;
+  d.p = s->training ? s->dropout : 0.f;
+  d.seed = s->seed + 0xA24BAED4963EE407ull * (uint64_t)(id + 1);
+  return d;
+}
+
+// weight + bias gradients and (optionally) the data gradient of y = x W^T + b
+int lin_bwd(const float* x, int ldx, const float* dy, int lddy, int M, int N, int K, const float* W, float* dW, float* db,
+            float* dx, int lddx, int accumulate, hipStream_t st) {
+  if (dW) OCEAN_TRY(linear_bwd_weight(dy, lddy, x, ldx, dW, M, N, K, st));
+  if (db) OCEAN_TRY(colsum_add(dy, lddy, M, N, db, st));
+  if (dx) OCEAN_TRY(linear_bwd_data(dy, lddy, W, dx, lddx, M, N, K, accumulate, st));
+  return OCEAN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ocean_mfa_fwd_workspace(const ocean_mfa_shape* s) { MfaPlan p; return make_plan(s, &p) == OCEAN_OK ? p.fwd_total : 0; }
+size_t ocean_mfa_bwd_workspace(const ocean_mfa_shape* s) { MfaPlan p; return make_plan(s, &p) == OCEAN_OK ? p.bwd_total : 0; }
+
+int ocean_mfa_fwd(const ocean_mfa_shape* s, const float* t, const float* sp, const float* lg, float* const* P_, float* ws,
+                  size_t ws_floats, float* out, void* stream) {
+  MfaPlan pl;
+  OCEAN_TRY(make_plan(s, &pl));
+  if (!t || !sp || !lg || !P_ || !ws || !out) return OCEAN_ERR_NULL;
+  if (ws_floats < pl.fwd_total) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, W = s->W, Wh = pl.Wh;
+  const size_t BW = (size_t)B * W;
+  const float* xin[3] = {t, sp, lg};
+  const int xd[3] = {s->td, s->sd, s->ld};
+  const DropoutP none = {0.f, 0};
+  for (int m = 0; m < 3; ++m) {
+    float* Pm = ws + pl.P + m * BW; float* Vm = ws + pl.V + m * BW; float* Am = ws + pl.A + m * BW;
+    OCEAN_TRY(linear_fwd(xin[m], xd[m], P_[2 * m], P_[2 * m + 1], Pm, W, B, W, xd[m], 0, st));
+    OCEAN_TRY(linear_fwd(Pm, W, P_[6 + 4 * m], P_[7 + 4 * m], Vm, W, B, W, W, 0, st));
+    OCEAN_TRY(dropout_inplace(Vm, W, B, W, W / s->heads, site(s, m), st));
+    OCEAN_TRY(linear_fwd(Vm, W, P_[8 + 4 * m], P_[9 + 4 * m], Am, W, B, W, W, 0, st));
+    OCEAN_TRY(dropout_inplace(Am, W, B, W, 1, site(s, 3 + m), st));
+    OCEAN_TRY(layernorm_fwd(Am, W, P_[18 + 2 * m], P_[19 + 2 * m], ws + pl.Nn + m * BW, W, ws + pl.lnst + (size_t)m * 2 * B, B, W, s->eps, none, st));
+  }
+  hipLaunchKernelGGL(cross_fwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.Nn, P_[26], ws + pl.G, ws + pl.cw, B, W);
+  OCEAN_LAUNCH_CHECK();
+  OCEAN_TRY(linear_fwd(ws + pl.G, W, P_[27], P_[28], ws + pl.Hd, Wh, 3 * B, Wh, W, 1, st));
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, ws + pl.Hd, P_[29], P_[30], ws + pl.G, ws + pl.ig,
+                     ws + pl.cat, B, W, Wh);
+  OCEAN_LAUNCH_CHECK();
+  OCEAN_TRY(linear_fwd(ws + pl.cat, 3 * W, P_[31], P_[32], ws + pl.F, W, B, W, 3 * W, 0, st));
+  OCEAN_TRY(linear_fwd(ws + pl.F, W, P_[33], P_[34], ws + pl.O1, W, B, W, W, 1, st));
+  OCEAN_TRY(dropout_inplace(ws + pl.O1, W, B, W, 1, site(s, 6), st));
+  OCEAN_TRY(linear_fwd(ws + pl.O1, W, P_[35], P_[36], ws + pl.O2, W, B, W, W, 0, st));
+  OCEAN_TRY(layernorm_fwd(ws + pl.O2, W, P_[24], P_[25], out, W, ws + pl.lnso, B, W, s->eps, none, st));
+  return OCEAN_OK;
+}
+
+int ocean_mfa_bwd(const ocean_mfa_shape* s, const float* t, const float* sp, const float* lg, float* const* P_, float* wf,
+                  float* wb, size_t wb_floats, const float* dout, float* const* G_, float* dt, float* dsp, float* dlg, void* stream) {
+  MfaPlan pl;
+  OCEAN_TRY(make_plan(s, &pl));
+  if (!t || !sp || !lg || !P_ || !wf || !wb || !dout || !G_) return OCEAN_ERR_NULL;
+  if (wb_floats < pl.bwd_total) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, W = s->W, Wh = pl.Wh;
+  const size_t BW = (size_t)B * W;
+  const DropoutP none = {0.f, 0};
+  float* e1 = wb + pl.e1; float* e2 = wb + pl.e2; float* d1 = wb + pl.d1; float* d2 = wb + pl.d2;
+  // output LayerNorm and MLP
+  OCEAN_TRY(layernorm_bwd(dout, W, wf + pl.O2, W, wf + pl.lnso, P_[24], e1, W, G_[24], G_[25], B, W, none, st));
+  OCEAN_TRY(lin_bwd(wf + pl.O1, W, e1, W, B, W, W, P_[35], G_[35], G_[36], e2, W, 0, st));
+  OCEAN_TRY(dropout_inplace(e2, W, B, W, 1, site(s, 6), st));
+  OCEAN_TRY(relu_bwd_inplace(e2, W, wf + pl.O1, W, B, W, st));
+  OCEAN_TRY(lin_bwd(wf + pl.F, W, e2, W, B, W, W, P_[33], G_[33], G_[34], e1, W, 0, st));
+  OCEAN_TRY(lin_bwd(wf + pl.cat, 3 * W, e1, W, B, W, 3 * W, P_[31], G_[31], G_[32], wb + pl.dcat, 3 * W, 0, st));
+  // feature gate
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, wb + pl.dcat, wf + pl.G, wf + pl.ig, wf + pl.Hd,
+                     P_[29], d1, wb + pl.dz, wb + pl.dHd, B, W, Wh);
+  OCEAN_LAUNCH_CHECK();
+  OCEAN_TRY(lin_bwd(wf + pl.Hd, Wh, wb + pl.dz, 1, 3 * B, 1, Wh, P_[29], G_[29], G_[30], nullptr, 0, 0, st));
+  OCEAN_TRY(lin_bwd(wf + pl.G, W, wb + pl.dHd, Wh, 3 * B, Wh, W, P_[27], G_[27], G_[28], d1, W, 1, st));
+  // cross-modal softmax and modality weights
+  OCEAN_TRY(zero_f32(wb + pl.dpi, 4, st));
+  hipLaunchKernelGGL(cross_bwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, d1, wf + pl.Nn, wf + pl.cw, P_[26], d2, wb + pl.dpi, B, W);
+  OCEAN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(modality_bwd_kernel, dim3(1), dim3(64), 0, st, wb + pl.dpi, P_[26], G_[26]);
+  OCEAN_LAUNCH_CHECK();
+  const float* xin[3] = {t, sp, lg};
+  const int xd[3] = {s->td, s->sd, s->ld};
+  float* dxin[3] = {dt, dsp, dlg};
+  for (int m = 0; m < 3; ++m) {
+    float* g2 = d2 + m * BW; float* g1 = d1 + m * BW;
+    OCEAN_TRY(layernorm_bwd(g2, W, wf + pl.A + m * BW, W, wf + pl.lnst + (size_t)m * 2 * B, P_[18 + 2 * m], g2, W, G_[18 + 2 * m],
+                            G_[19 + 2 * m], B, W, none, st));
+    OCEAN_TRY(dropout_inplace(g2, W, B, W, 1, site(s, 3 + m), st));
+    OCEAN_TRY(lin_bwd(wf + pl.V + m * BW, W, g2, W, B, W, W, P_[8 + 4 * m], G_[8 + 4 * m], G_[9 + 4 * m], g1, W, 0, st));
+    OCEAN_TRY(dropout_inplace(g1, W, B, W, W / s->heads, site(s, m), st));
+    OCEAN_TRY(lin_bwd(wf + pl.P + m * BW, W, g1, W, B, W, W, P_[6 + 4 * m], G_[6 + 4 * m], G_[7 + 4 * m], g2, W, 0, st));
+    OCEAN_TRY(lin_bwd(xin[m], xd[m], g2, W, B, W, xd[m], P_[2 * m], G_[2 * m], G_[2 * m + 1], dxin[m], xd[m], 0, st));
+  }
+  return OCEAN_OK;
+}
+
+}  // extern "C"

@@ -20,3 +20,21 @@ int zero_f32(float* dst, size_t n, hipStream_t s);
 int zero_f64(double* dst, size_t n, hipStream_t s);
 // dst[M,N] (ld) = src[M,N] (ld) ; or dst += src
 int copy2d(float* dst, int ldd, const float* src, int lds, int M, int N, int accumulate, hipStream_t s);
+
+// ---------------------------------------------------------------- row-wise ops (one 64-lane wave per row)
+// y = LayerNorm(dropout(x)) * gamma + beta; stats[row] = {mean, rstd}.  in_drop.p == 0: no dropout.
+int layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* stats,
+                  int rows, int W, float eps, DropoutP in_drop, hipStream_t s);
+// dx = d/dx of the above (dropout mask re-applied); dgamma/dbeta accumulated.  dx may alias dy.
+int layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* stats, const float* gamma,
+                  float* dx, int lddx, float* dgamma, float* dbeta, int rows, int W, DropoutP in_drop, hipStream_t s);
+// y = x / max(||x||_2, eps) per row; norms[row] saved
+int l2norm_fwd(const float* x, int ldx, float* y, int ldy, float* norms, int rows, int W, float eps, hipStream_t s);
+// dx = (dy - y * (y . dy)) / max(norm, eps); dx may alias dy
+int l2norm_bwd(const float* dy, int lddy, const float* y, int ldy, const float* norms, float* dx, int lddx,
+               int rows, int W, float eps, hipStream_t s);
+// x *= keep(mask)/(1-p) elementwise over [M,N] (ld); idx = row*N + col.  `group` > 1: one mask value per
+// `group` consecutive columns (per-head attention-weight dropout on a length-1 sequence).
+int dropout_inplace(float* x, int ld, int M, int N, int group, DropoutP d, hipStream_t s);
+// out[G, C] = mean over the middle axis of a[G, n, C]
+int mean_mid(const float* a, float* out, int G, int n, int C, hipStream_t s);

@@ -1,0 +1,80 @@
+// Gradient clipping + Adam in two launches over a chunk table.
+//
+// The update step of OnlineLearner / Trainer (online_learner.py:325-335,402-412;
+// trainer.py:416-426) is clip_grad_norm_(max_norm) followed by torch.optim.Adam
+// (coupled L2 weight decay).  Here: one launch accumulates the global squared
+// gradient norm in fp64, one launch applies clip coefficient + weight decay +
+// moment updates + parameter update, 28 bytes of HBM traffic per parameter.
+// The table has one row per chunk of at most kChunk consecutive elements of one
+// tensor: {param, grad, exp_avg, exp_avg_sq} addresses and the element count.
+#include "../../include/ocean_hip.h"
+#include "common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const ocean_adam_chunk* __restrict__ tab, double* __restrict__ out) {
+  __shared__ float red[4];
+  const ocean_adam_chunk c = tab[blockIdx.x];
+  const float* g = reinterpret_cast<const float*>(c.grad);
+  float s = 0.f;
+  for (long i = threadIdx.x; i < c.n; i += 256) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, (double)(red[0] + red[1] + red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(const ocean_adam_chunk* __restrict__ tab, const double* __restrict__ sqnorm,
+                                                        float max_norm, float lr, float b1, float b2, float eps, float wd,
+                                                        float bc1, float bc2, int write_clipped) {
+  const ocean_adam_chunk c = tab[blockIdx.x];
+  float* p = reinterpret_cast<float*>(c.param);
+  float* g = reinterpret_cast<float*>(c.grad);
+  float* m = reinterpret_cast<float*>(c.exp_avg);
+  float* v = reinterpret_cast<float*>(c.exp_avg_sq);
+  float coef = 1.f;
+  if (max_norm > 0.f && sqnorm) coef = fminf(1.f, max_norm / ((float)sqrt(sqnorm[0]) + 1e-6f));
+  const float step = lr / bc1, rs2 = 1.0f / sqrtf(bc2);
+  for (long i = threadIdx.x; i < c.n; i += 256) {
+    const float gc = g[i] * coef;
+    if (write_clipped) g[i] = gc;
+    const float pv = p[i];
+    const float gd = fmaf(wd, pv, gc);
+    const float mi = b1 * m[i] + (1.f - b1) * gd;
+    const float vi = b2 * v[i] + (1.f - b2) * gd * gd;
+    m[i] = mi; v[i] = vi;
+    p[i] = pv - step * mi / (sqrtf(vi) * rs2 + eps);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ocean_grad_sqnorm(const ocean_adam_chunk* table, int n_chunks, double* sqnorm, void* stream) {
+  if (!table || !sqnorm) return OCEAN_ERR_NULL;
+  if (n_chunks <= 0) return OCEAN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, sqnorm);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int ocean_clip_adam_step(const ocean_adam_chunk* table, int n_chunks, const double* sqnorm, float max_norm, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int step, int write_clipped, void* stream) {
+  if (!table) return OCEAN_ERR_NULL;
+  if (n_chunks <= 0 || step < 1) return OCEAN_ERR_BAD_SHAPE;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, sqnorm, max_norm, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2, write_clipped);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+}  // extern "C"

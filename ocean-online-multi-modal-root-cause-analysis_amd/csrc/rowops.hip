@@ -1,0 +1,188 @@
+// Row-wise kernels shared by the attention / fusion / head drivers: LayerNorm,
+// L2 normalisation, dropout, token mean.  One 64-lane wave per row, lanes
+// stride the row (coalesced), reductions by wavefront shuffles; rows are
+// re-read from L1 rather than cached in registers so any width works.
+#include "ops.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+constexpr int kWaves = 4;
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y, int ldy,
+                                                     float* __restrict__ stats, int rows, int W, float eps, DropoutP dp) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  auto val = [&](int c) { float v = xr[c]; if (dp.p > 0.f) v *= dropout_keep(dp, (uint64_t)row * W + c); return v; };
+  float s = 0.f;
+  for (int c = lane; c < W; c += 64) s += val(c);
+  const float mean = wave_sum(s) / (float)W;
+  float q = 0.f;
+  for (int c = lane; c < W; c += 64) { const float d = val(c) - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + eps);
+  for (int c = lane; c < W; c += 64) y[(long)row * ldy + c] = (val(c) - mean) * rstd * gamma[c] + beta[c];
+  if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// Each wave walks rows row0 + w, row0 + w + kWaves, ... of its block's chunk so the
+// per-column gamma/beta partial sums stay in registers (up to 16 columns per lane).
+constexpr int kLnRowsPerBlock = 32;
+constexpr int kMaxColsPerLane = 16;
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     float* __restrict__ dx, int lddx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int rows, int W, DropoutP dp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float pg[kMaxColsPerLane], pb[kMaxColsPerLane];
+#pragma unroll
+  for (int k = 0; k < kMaxColsPerLane; ++k) { pg[k] = 0.f; pb[k] = 0.f; }
+  const int r0 = blockIdx.x * kLnRowsPerBlock, r1 = min(rows, r0 + kLnRowsPerBlock);
+  for (int row = r0 + wave; row < r1; row += kWaves) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float* xr = x + (long)row * ldx;
+    const float* gr = dy + (long)row * lddy;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxColsPerLane; ++k) {
+      const int c = lane + 64 * k;
+      if (c < W) {
+        float xv = xr[c];
+        if (dp.p > 0.f) xv *= dropout_keep(dp, (uint64_t)row * W + c);
+        const float xh = (xv - mean) * rstd, g = gr[c];
+        pg[k] += g * xh; pb[k] += g;
+        const float dxh = g * gamma[c];
+        s1 += dxh; s2 += dxh * xh;
+      }
+    }
+    s1 = wave_sum(s1) / (float)W; s2 = wave_sum(s2) / (float)W;
+#pragma unroll
+    for (int k = 0; k < kMaxColsPerLane; ++k) {
+      const int c = lane + 64 * k;
+      if (c < W) {
+        float keep = 1.f, xv = xr[c];
+        if (dp.p > 0.f) { keep = dropout_keep(dp, (uint64_t)row * W + c); xv *= keep; }
+        const float xh = (xv - mean) * rstd;
+        dx[(long)row * lddx + c] = rstd * (gr[c] * gamma[c] - s1 - xh * s2) * keep;
+      }
+    }
+  }
+  __shared__ float red[2][kWaves][64 * kMaxColsPerLane];
+#pragma unroll
+  for (int k = 0; k < kMaxColsPerLane; ++k) {
+    const int c = lane + 64 * k;
+    if (c < W) { red[0][wave][c] = pg[k]; red[1][wave][c] = pb[k]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < W; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) { a += red[0][w][c]; b += red[1][w][c]; }
+    if (dgamma) unsafeAtomicAdd(dgamma + c, a);
+    if (dbeta) unsafeAtomicAdd(dbeta + c, b);
+  }
+}
+
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                         float* __restrict__ norms, int rows, int W, float eps) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * ldx;
+  float q = 0.f;
+  for (int c = lane; c < W; c += 64) q += xr[c] * xr[c];
+  const float nrm = sqrtf(wave_sum(q));
+  const float inv = 1.0f / fmaxf(nrm, eps);
+  for (int c = lane; c < W; c += 64) y[(long)row * ldy + c] = xr[c] * inv;
+  if (lane == 0) norms[row] = nrm;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                                         const float* __restrict__ norms, float* __restrict__ dx, int lddx,
+                                                         int rows, int W, float eps) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* gr = dy + (long)row * lddy;
+  const float* yr = y + (long)row * ldy;
+  float d = 0.f;
+  for (int c = lane; c < W; c += 64) d += gr[c] * yr[c];
+  d = wave_sum(d);
+  const float nrm = norms[row];
+  // below eps the forward is x/eps (linear): no projection term
+  const float inv = 1.0f / fmaxf(nrm, eps);
+  const float proj = nrm > eps ? d : 0.f;
+  for (int c = lane; c < W; c += 64) dx[(long)row * lddx + c] = (gr[c] - yr[c] * proj) * inv;
+}
+
+__global__ void dropout_kernel(float* __restrict__ x, int ld, int M, int N, int group, DropoutP d) {
+  const long n = (long)M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / N), c = (int)(i % N);
+    const uint64_t idx = group > 1 ? (uint64_t)r * (N / group) + c / group : (uint64_t)i;
+    x[(long)r * ld + c] *= dropout_keep(d, idx);
+  }
+}
+
+__global__ void mean_mid_kernel2(const float* __restrict__ a, float* __restrict__ out, int n, int C) {
+  const int b = blockIdx.x;
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float* p = a + (long)b * n * C + c;
+  float s = 0.f;
+  for (int t = 0; t < n; ++t) s += p[(long)t * C];
+  out[(long)b * C + c] = s / (float)n;
+}
+
+}  // namespace
+
+int layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* stats,
+                  int rows, int W, float eps, DropoutP in_drop, hipStream_t s) {
+  if (rows <= 0 || W <= 0) return OCEAN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, kWaves)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, stats, rows, W, eps, in_drop);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* stats, const float* gamma,
+                  float* dx, int lddx, float* dgamma, float* dbeta, int rows, int W, DropoutP in_drop, hipStream_t s) {
+  if (rows <= 0 || W <= 0) return OCEAN_ERR_BAD_SHAPE;
+  if (W > 64 * kMaxColsPerLane) return OCEAN_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, kLnRowsPerBlock)), dim3(256), 0, s, dy, lddy, x, ldx, stats, gamma, dx, lddx,
+                     dgamma, dbeta, rows, W, in_drop);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int l2norm_fwd(const float* x, int ldx, float* y, int ldy, float* norms, int rows, int W, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(ceil_div(rows, kWaves)), dim3(256), 0, s, x, ldx, y, ldy, norms, rows, W, eps);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int l2norm_bwd(const float* dy, int lddy, const float* y, int ldy, const float* norms, float* dx, int lddx,
+               int rows, int W, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(ceil_div(rows, kWaves)), dim3(256), 0, s, dy, lddy, y, ldy, norms, dx, lddx, rows, W, eps);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int dropout_inplace(float* x, int ld, int M, int N, int group, DropoutP d, hipStream_t s) {
+  if (d.p <= 0.f) return OCEAN_OK;
+  long g = ((long)M * N + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(dropout_kernel, dim3((int)g), dim3(256), 0, s, x, ld, M, N, group, d);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int mean_mid(const float* a, float* out, int G, int n, int C, hipStream_t s) {
+  hipLaunchKernelGGL(mean_mid_kernel2, dim3(G, ceil_div(C, 64)), dim3(64), 0, s, a, out, n, C);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}

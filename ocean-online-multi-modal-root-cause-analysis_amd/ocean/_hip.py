@@ -63,6 +63,62 @@ def _declare(lib) -> None:
                                    POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p]
 
 
+class MfaShape(ctypes.Structure):
+    _fields_ = [("B", c_int), ("td", c_int), ("sd", c_int), ("ld", c_int), ("W", c_int), ("heads", c_int),
+                ("training", c_int), ("dropout", c_float), ("eps", c_float), ("seed", c_uint64)]
+
+
+class FusionShape(ctypes.Structure):
+    _fields_ = [("B", c_int), ("td", c_int), ("sd", c_int), ("ld", c_int), ("E", c_int), ("Pd", c_int),
+                ("heads", c_int), ("training", c_int), ("contrastive", c_int), ("dropout", c_float),
+                ("eps", c_float), ("seed", c_uint64)]
+
+
+class InfoNceShape(ctypes.Structure):
+    _fields_ = [("B", c_int), ("Bp", c_int), ("P", c_int), ("K", c_int), ("label_offset", c_int),
+                ("mean_rows", c_int), ("tau", c_float)]
+
+
+class HeadShape(ctypes.Structure):
+    _fields_ = [("B", c_int), ("E", c_int), ("h1", c_int), ("h2", c_int), ("S", c_int), ("training", c_int),
+                ("dropout", c_float), ("seed", c_uint64)]
+
+
+class AdamChunk(ctypes.Structure):
+    _fields_ = [("param", c_uint64), ("grad", c_uint64), ("exp_avg", c_uint64), ("exp_avg_sq", c_uint64),
+                ("n", ctypes.c_int64)]
+
+
+def _declare_rest(lib) -> None:
+    vp, tp = c_void_p, POINTER(c_void_p)
+
+    def sig(name, res, *args):
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, list(args)
+
+    mp, fp_, ip, hp = POINTER(MfaShape), POINTER(FusionShape), POINTER(InfoNceShape), POINTER(HeadShape)
+    sig("ocean_mfa_fwd_workspace", c_size_t, mp)
+    sig("ocean_mfa_bwd_workspace", c_size_t, mp)
+    sig("ocean_mfa_fwd", c_int, mp, vp, vp, vp, tp, vp, c_size_t, vp, vp)
+    sig("ocean_mfa_bwd", c_int, mp, vp, vp, vp, tp, vp, vp, c_size_t, vp, tp, vp, vp, vp, vp)
+    sig("ocean_fusion_fwd_workspace", c_size_t, fp_)
+    sig("ocean_fusion_bwd_workspace", c_size_t, fp_)
+    sig("ocean_fusion_fwd", c_int, fp_, vp, vp, vp, tp, vp, c_size_t, vp, vp, vp, vp)
+    sig("ocean_fusion_bwd", c_int, fp_, vp, vp, vp, tp, vp, vp, vp, vp, c_size_t, vp, vp, vp, tp, vp, vp, vp, vp)
+    sig("ocean_infonce_workspace", c_size_t, ip)
+    sig("ocean_infonce_bwd_workspace", c_size_t, ip)
+    sig("ocean_infonce_fwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp)
+    sig("ocean_infonce_bwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp, vp, vp)
+    sig("ocean_head_workspace", c_size_t, hp)
+    sig("ocean_head_bwd_workspace", c_size_t, hp)
+    sig("ocean_head_fwd", c_int, hp, vp, tp, vp, c_size_t, vp, vp, vp)
+    sig("ocean_head_bwd", c_int, hp, vp, tp, vp, vp, c_size_t, vp, vp, vp, tp, vp, vp)
+    sig("ocean_bce_fwd", c_int, vp, vp, c_long, c_long, vp, vp)
+    sig("ocean_bce_bwd", c_int, vp, vp, vp, c_long, c_long, vp, vp)
+    sig("ocean_grad_sqnorm", c_int, vp, c_int, vp, vp)
+    sig("ocean_clip_adam_step", c_int, vp, c_int, vp, c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_int, vp)
+
+
 def _declare_gnn(lib) -> None:
     gp = POINTER(GnnShape)
     lib.ocean_gnn_fwd_workspace.restype = c_size_t
@@ -87,6 +143,7 @@ def lib():
         _lib = ctypes.CDLL(_LIB_PATH)
         _declare(_lib)
         _declare_gnn(_lib)
+        _declare_rest(_lib)
     return _lib
 
 
@@ -115,6 +172,11 @@ def ptr_table(tensors: Sequence[Optional[torch.Tensor]], name: str):
     for i, t in enumerate(tensors):
         arr[i] = dev_ptr(t, f"{name}[{i}]").value if t is not None else None
     return arr
+
+
+def new_seed(p: float) -> int:
+    """A fresh dropout seed from torch's CPU generator (0 when dropout is inactive)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
 
 
 def stream() -> c_void_p:

@@ -1,0 +1,279 @@
+"""Graph fusion with contrastive (InfoNCE) learning, on MI355X.
+
+Interface and state_dict keys follow the reference's ProjectionHead,
+InfoNCELoss, ContrastiveLearningModule and GraphFusionModule
+(ocean/models/components/graph_fusion.py:17-92, 95-162, 165-273, 276-501).
+torch sub-modules are parameter containers; the arithmetic runs in
+libocean_hip.so (ocean_fusion_fwd / ocean_fusion_bwd, ocean_infonce_*).
+
+Two documented differences from the reference, both where the reference
+fails: the memory-bank write is a modulo ring for every batch size (the
+reference raises as soon as ptr + 3B > 2*16, graph_fusion.py:263-273), and
+`negatives='in_batch'` selects InfoNCELoss's in-batch branch
+(graph_fusion.py:144-157), which the reference model never reaches.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Any, Callable, Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import _hip, ops
+
+
+class ProjectionHead(nn.Module):
+    """Linear -> ReLU -> Dropout -> Linear -> L2 normalise (graph_fusion.py:23-92)."""
+
+    def __init__(self, input_dim: int, projection_dim: int = 256, hidden_dim: Optional[int] = None, num_layers: int = 2,
+                 activation: str = "relu", dropout: float = 0.1):
+        super().__init__()
+        hidden_dim = input_dim if hidden_dim is None else hidden_dim
+        layers, cur = [], input_dim
+        for i in range(num_layers):
+            if i == num_layers - 1:
+                layers.append(nn.Linear(cur, projection_dim))
+            else:
+                layers.append(nn.Linear(cur, hidden_dim))
+                layers.append({"relu": nn.ReLU, "gelu": nn.GELU, "leaky_relu": nn.LeakyReLU}.get(activation, nn.ReLU)())
+                if dropout > 0:
+                    layers.append(nn.Dropout(dropout))
+                cur = hidden_dim
+        self.projection = nn.Sequential(*layers)
+        self.normalize = True
+        self.num_layers, self.activation_name = num_layers, activation
+
+    def forward(self, x):
+        raise NotImplementedError("ProjectionHead is executed inside GraphFusionModule's fused HIP driver")
+
+
+class InfoNCELoss(nn.Module):
+    def __init__(self, temperature: float = 0.1, reduction: str = "mean"):
+        super().__init__()
+        self.temperature, self.reduction = temperature, reduction
+
+    def forward(self, anchor: torch.Tensor, positive: torch.Tensor, negative: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.reduction not in ("mean", "sum"):
+            raise NotImplementedError("reduction='none' is not provided by the fused kernel")
+        loss = ops.infonce(anchor, positive, negative, self.temperature)
+        return loss * anchor.shape[0] if self.reduction == "sum" else loss
+
+
+class ContrastiveLearningModule(nn.Module):
+    def __init__(self, modality_dims: Dict[str, int], projection_dim: int = 256, temperature: float = 0.1,
+                 num_negatives: int = 16):
+        super().__init__()
+        self.modality_dims, self.projection_dim, self.num_negatives = modality_dims, projection_dim, num_negatives
+        self.projection_heads = nn.ModuleDict({m: ProjectionHead(d, projection_dim) for m, d in modality_dims.items()})
+        self.infonce_loss = InfoNCELoss(temperature)
+        self.register_buffer("memory_bank", torch.randn(num_negatives, projection_dim))
+        self.register_buffer("memory_ptr", torch.zeros(1, dtype=torch.long))
+        self.negatives = "bank"                    # or "in_batch"
+        # data-parallel hooks (in-batch negatives): gather [B_loc,P] -> [B_glob,P] keeping autograd, and this rank's row offset
+        self.gather_positives: Optional[Callable[[torch.Tensor], torch.Tensor]] = None
+        self.rank_row_offset: Callable[[int], int] = lambda local_rows: 0
+        self._ptr_host: Optional[int] = None       # host shadow of memory_ptr (avoids a device read per step)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._ptr_host = None
+
+    def _get_negatives(self) -> torch.Tensor:
+        return self.memory_bank.clone().detach()
+
+    def losses_from_projections(self, projections: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        names = list(projections.keys())
+        losses = {}
+        neg = self._get_negatives() if self.negatives == "bank" else None
+        for i, a in enumerate(names):
+            for b in names[i + 1:]:
+                pa, pb = projections[a], projections[b]
+                if neg is not None:
+                    losses[f"{a}_{b}_contrastive"] = ops.infonce(pa, pb, neg, self.infonce_loss.temperature)
+                else:
+                    allb = self.gather_positives(pb) if self.gather_positives is not None else pb
+                    losses[f"{a}_{b}_contrastive"] = ops.infonce(pa, allb, None, self.infonce_loss.temperature,
+                                                                  label_offset=self.rank_row_offset(pa.shape[0]))
+        return losses
+
+    def _update_memory_bank(self, projections: Dict[str, torch.Tensor]) -> None:
+        """Ring write of cat(projections) at memory_ptr.  Contents equal the
+        reference's on every step it survives; the stored pointer follows its
+        formula (including the out-of-range value K when ptr + R == 2K)."""
+        if not projections:
+            return
+        rows = torch.cat([p.detach() for p in projections.values()], dim=0)
+        K, R = self.num_negatives, rows.shape[0]
+        if self._ptr_host is None:
+            self._ptr_host = int(self.memory_ptr.item())
+        ptr = self._ptr_host
+        start = ptr
+        if R > K:                                   # only the last K rows survive a full lap
+            rows, start = rows[R - K:], (ptr + R - K) % K
+        idx = (start + torch.arange(rows.shape[0], device=rows.device)) % K
+        self.memory_bank.index_copy_(0, idx, rows.to(self.memory_bank.dtype))
+        if ptr + R <= K:
+            new_ptr = (ptr + R) % K
+        elif ptr + R <= 2 * K:
+            new_ptr = ptr + R - K
+        else:
+            new_ptr = (ptr + R) % K
+        self._ptr_host = new_ptr
+        self.memory_ptr.fill_(new_ptr)
+
+    def forward(self, modality_features, return_projections: bool = False):
+        raise NotImplementedError("projections are produced by GraphFusionModule's fused driver; "
+                                  "use losses_from_projections / _update_memory_bank")
+
+
+class _FusionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, s, l, module, contrastive, *params):
+        L = _hip.lib()
+        sh = module._shape(t, s, l, contrastive)
+        ctx.set_materialize_grads(False)
+        dev = t.device
+        ws = torch.empty(L.ocean_fusion_fwd_workspace(ctypes.byref(sh)), device=dev, dtype=torch.float32)
+        fused = torch.empty(sh.B, sh.E, device=dev, dtype=torch.float32)
+        X = torch.empty(sh.B, 3, sh.E, device=dev, dtype=torch.float32)
+        Zp = torch.empty(3, sh.B, sh.Pd, device=dev, dtype=torch.float32) if contrastive else None
+        _hip.check(L.ocean_fusion_fwd(ctypes.byref(sh), _hip.dev_ptr(t, "temporal"), _hip.dev_ptr(s, "spatial"), _hip.dev_ptr(l, "logs"),
+                                      _hip.ptr_table(params, "fusion param"), _hip.dev_ptr(ws), ws.numel(), _hip.dev_ptr(fused),
+                                      _hip.dev_ptr(X), _hip.dev_ptr(Zp), _hip.stream()), "ocean_fusion_fwd")
+        ctx.sh, ctx.contrastive = sh, contrastive
+        ctx.save_for_backward(t, s, l, ws, X, Zp if contrastive else X, *params)
+        if contrastive:
+            return fused, X, Zp
+        return fused, X, torch.empty(0, device=dev)
+
+    @staticmethod
+    def backward(ctx, dfused, dX, dZp):
+        L = _hip.lib()
+        t, s, l, ws, X, Zp, *params = ctx.saved_tensors
+        sh = ctx.sh
+        wb = torch.empty(L.ocean_fusion_bwd_workspace(ctypes.byref(sh)), device=t.device, dtype=torch.float32)
+        grads = [torch.zeros_like(p) for p in params]
+        dt = torch.empty_like(t) if ctx.needs_input_grad[0] else None
+        ds = torch.empty_like(s) if ctx.needs_input_grad[1] else None
+        dl = torch.empty_like(l) if ctx.needs_input_grad[2] else None
+        c = lambda g: None if g is None else g.contiguous()
+        if not ctx.contrastive:
+            dZp = None
+        _hip.check(L.ocean_fusion_bwd(ctypes.byref(sh), _hip.dev_ptr(t), _hip.dev_ptr(s), _hip.dev_ptr(l),
+                                      _hip.ptr_table(params, "fusion param"), _hip.dev_ptr(ws), _hip.dev_ptr(X),
+                                      _hip.dev_ptr(Zp if ctx.contrastive else None), _hip.dev_ptr(wb), wb.numel(),
+                                      _hip.dev_ptr(c(dfused)), _hip.dev_ptr(c(dX)), _hip.dev_ptr(c(dZp)),
+                                      _hip.ptr_table(grads, "fusion grad"), _hip.dev_ptr(dt), _hip.dev_ptr(ds), _hip.dev_ptr(dl),
+                                      _hip.stream()), "ocean_fusion_bwd")
+        n_head = 12
+        out = [dt, ds, dl, None, None]
+        for i, g in enumerate(grads):
+            used = ctx.contrastive or i < 22       # projection-head parameters only receive gradients when they ran
+            out.append(g if (used and ctx.needs_input_grad[5 + i]) else None)
+        return tuple(out)
+
+
+class GraphFusionModule(nn.Module):
+    def __init__(self, temporal_dim: int, spatial_dim: int, log_dim: int, fusion_dim: int = 256, projection_dim: int = 128,
+                 temperature: float = 0.1, fusion_strategy: str = "attention", dropout: float = 0.1):
+        super().__init__()
+        self.temporal_dim, self.spatial_dim, self.log_dim = temporal_dim, spatial_dim, log_dim
+        self.fusion_dim, self.projection_dim, self.fusion_strategy = fusion_dim, projection_dim, fusion_strategy
+        mk = lambda d: nn.Sequential(nn.Linear(d, fusion_dim), nn.ReLU(), nn.Dropout(dropout), nn.LayerNorm(fusion_dim))
+        self.temporal_processor, self.spatial_processor, self.log_processor = mk(temporal_dim), mk(spatial_dim), mk(log_dim)
+        self.contrastive_module = ContrastiveLearningModule(
+            {"temporal": fusion_dim, "spatial": fusion_dim, "log": fusion_dim}, projection_dim, temperature)
+        if fusion_strategy == "attention":
+            self.attention_fusion = nn.MultiheadAttention(embed_dim=fusion_dim, num_heads=8, dropout=dropout, batch_first=True)
+            self.attention_norm = nn.LayerNorm(fusion_dim)
+        elif fusion_strategy == "concatenate":
+            self.fusion_layer = nn.Sequential(nn.Linear(fusion_dim * 3, fusion_dim), nn.ReLU(), nn.Dropout(dropout),
+                                              nn.LayerNorm(fusion_dim))
+        elif fusion_strategy == "gate":
+            self.gate_network = nn.Sequential(nn.Linear(fusion_dim * 3, fusion_dim), nn.Sigmoid())
+            self.value_network = nn.Sequential(nn.Linear(fusion_dim * 3, fusion_dim), nn.Tanh())
+        self.output_projection = nn.Sequential(nn.Linear(fusion_dim, fusion_dim), nn.ReLU(), nn.Dropout(dropout),
+                                               nn.Linear(fusion_dim, fusion_dim))
+        self.mi_estimator = nn.Sequential(nn.Linear(fusion_dim * 2, fusion_dim), nn.ReLU(), nn.Linear(fusion_dim, 1))
+        self.compute_mutual_information = True
+
+    def _param_list(self):
+        ps = []
+        for proc in (self.temporal_processor, self.spatial_processor, self.log_processor):
+            ps += [proc[0].weight, proc[0].bias, proc[3].weight, proc[3].bias]
+        af, op = self.attention_fusion, self.output_projection
+        ps += [af.in_proj_weight, af.in_proj_bias, af.out_proj.weight, af.out_proj.bias,
+               self.attention_norm.weight, self.attention_norm.bias, op[0].weight, op[0].bias, op[3].weight, op[3].bias]
+        for m in ("temporal", "spatial", "log"):
+            pr = self.contrastive_module.projection_heads[m].projection
+            ps += [pr[0].weight, pr[0].bias, pr[3].weight, pr[3].bias]
+        return ps
+
+    def _shape(self, t, s, l, contrastive) -> _hip.FusionShape:
+        sh = _hip.FusionShape()
+        sh.B, sh.td, sh.sd, sh.ld = t.shape[0], t.shape[1], s.shape[1], l.shape[1]
+        sh.E, sh.Pd, sh.heads = self.fusion_dim, self.projection_dim, self.attention_fusion.num_heads
+        sh.training, sh.contrastive = int(self.training), int(contrastive)
+        sh.dropout = float(self.output_projection[2].p) if self.training else 0.0
+        sh.eps = self.attention_norm.eps
+        sh.seed = _hip.new_seed(sh.dropout)
+        return sh
+
+    def forward(self, temporal_features: torch.Tensor, spatial_features: torch.Tensor, log_features: torch.Tensor,
+                compute_contrastive_loss: bool = True) -> Dict[str, Any]:
+        if self.fusion_strategy != "attention":
+            raise NotImplementedError("the HIP path implements fusion_strategy='attention' (the one OCEANModel uses)")
+        ph = self.contrastive_module.projection_heads["temporal"]
+        if ph.num_layers != 2 or ph.activation_name != "relu":
+            raise NotImplementedError("projection heads: 2 layers with ReLU")
+        t, s, l = (x.contiguous().float() for x in (temporal_features, spatial_features, log_features))
+        fused, X, Zp = _FusionFunction.apply(t, s, l, self, bool(compute_contrastive_loss), *self._param_list())
+        processed = {"temporal": X[:, 0], "spatial": X[:, 1], "log": X[:, 2]}
+        results: Dict[str, Any] = {"fused_representation": fused, "processed_features": processed}
+        if compute_contrastive_loss:
+            cm = self.contrastive_module
+            projections = {"temporal": Zp[0], "spatial": Zp[1], "log": Zp[2]}
+            results["contrastive_losses"] = cm.losses_from_projections(projections)
+            if cm.training and cm.negatives == "bank":
+                cm._update_memory_bank(projections)
+            results["projections"] = projections
+            results["mutual_information"] = self._mutual_information(fused, processed) if self.compute_mutual_information else {}
+        return results
+
+    def _mutual_information(self, fused, processed) -> Dict[str, torch.Tensor]:
+        """MINE estimates of graph_fusion.py:475-501 (diagnostics only: they enter no loss)."""
+        out = {}
+        w0, b0, w1, b1 = (p.detach() for p in (self.mi_estimator[0].weight, self.mi_estimator[0].bias,
+                                               self.mi_estimator[2].weight, self.mi_estimator[2].bias))
+        B, E = fused.shape
+        with torch.no_grad():
+            f = fused.detach()
+            for k in ("temporal", "spatial", "log"):
+                m = processed[k].detach()
+                perm = torch.randperm(B, device=f.device)
+                pairs = torch.cat([torch.cat([f, m], 1), torch.cat([f, m[perm]], 1)], 0).contiguous()
+                hid = torch.empty(2 * B, E, device=f.device)
+                _hip.gemm(pairs, w0, hid, 2 * B, E, 2 * E, bias=b0, relu=True)
+                sc = torch.empty(2 * B, 1, device=f.device)
+                _hip.gemm(hid, w1, sc, 2 * B, 1, E, bias=b1)
+                out[f"{k}_mi"] = sc[:B].mean() - torch.log(torch.exp(sc[B:]).mean() + 1e-8)
+        return out
+
+    def get_fusion_analysis(self, temporal_features, spatial_features, log_features) -> Dict[str, Any]:
+        with torch.no_grad():
+            r = self.forward(temporal_features, spatial_features, log_features)
+        a = {"modality_contributions": {k: torch.norm(v, dim=1).mean().item() for k, v in r["processed_features"].items()},
+             "fusion_strategy": self.fusion_strategy}
+        if "mutual_information" in r:
+            a["mutual_information"] = {k: v.item() for k, v in r["mutual_information"].items()}
+        if "contrastive_losses" in r:
+            a["contrastive_losses"] = {k: v.item() for k, v in r["contrastive_losses"].items()}
+        return a
+
+    def get_model_info(self) -> Dict[str, Any]:
+        total = sum(p.numel() for p in self.parameters())
+        return {"model_type": "GraphFusionModule", "temporal_dim": self.temporal_dim, "spatial_dim": self.spatial_dim,
+                "log_dim": self.log_dim, "fusion_dim": self.fusion_dim, "fusion_strategy": self.fusion_strategy,
+                "total_parameters": total,
+                "trainable_parameters": sum(p.numel() for p in self.parameters() if p.requires_grad)}

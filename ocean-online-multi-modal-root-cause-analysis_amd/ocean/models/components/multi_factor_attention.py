@@ -1,0 +1,194 @@
+"""Multi-factor attention over the temporal / spatial / log modality vectors, on MI355X.
+
+Interface and state_dict keys follow the reference's MultiFactorAttention and
+the helper classes it instantiates (ocean/models/components/
+multi_factor_attention.py:17-215, 218-440).  The helper classes here are
+parameter containers (the reference constructs three CrossModalAttention
+blocks it never calls, :264-266 - their parameters must still exist in the
+state_dict); the arithmetic of MultiFactorAttention.forward runs in
+libocean_hip.so (ocean_mfa_fwd / ocean_mfa_bwd).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Any, Dict
+
+import torch
+import torch.nn as nn
+
+from ... import _hip
+
+
+class ScaledDotProductAttention(nn.Module):
+    def __init__(self, d_model: int, dropout: float = 0.1):
+        super().__init__()
+        self.d_model = d_model
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("container only: MultiFactorAttention drives the HIP kernels")
+
+
+class MultiHeadAttention(nn.Module):
+    """w_q / w_k / w_v / w_o of multi_factor_attention.py:96-101.  On the model
+    path it only ever sees a length-1 sequence, where softmax == 1 and w_q / w_k
+    cannot influence the output."""
+
+    def __init__(self, d_model: int, num_heads: int, dropout: float = 0.1, bias: bool = True):
+        super().__init__()
+        assert d_model % num_heads == 0, "d_model must be divisible by num_heads"
+        self.d_model, self.num_heads, self.d_k = d_model, num_heads, d_model // num_heads
+        self.w_q = nn.Linear(d_model, d_model, bias=bias)
+        self.w_k = nn.Linear(d_model, d_model, bias=bias)
+        self.w_v = nn.Linear(d_model, d_model, bias=bias)
+        self.w_o = nn.Linear(d_model, d_model, bias=bias)
+        self.attention = ScaledDotProductAttention(self.d_k, dropout)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("container only: MultiFactorAttention drives the HIP kernels")
+
+
+class CrossModalAttention(nn.Module):
+    """Constructed but never called by the reference model (multi_factor_attention.py:264-266)."""
+
+    def __init__(self, d_model: int, num_heads: int = 8, dropout: float = 0.1):
+        super().__init__()
+        self.d_model, self.num_heads = d_model, num_heads
+        self.multihead_attention = MultiHeadAttention(d_model, num_heads, dropout)
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.feed_forward = nn.Sequential(nn.Linear(d_model, d_model * 4), nn.ReLU(), nn.Dropout(dropout),
+                                          nn.Linear(d_model * 4, d_model), nn.Dropout(dropout))
+        self.ff_layer_norm = nn.LayerNorm(d_model)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("not on the OCEAN model path")
+
+
+class _MfaFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, s, l, module, *params):
+        L = _hip.lib()
+        sh = module._shape(t, s, l)
+        ws = torch.empty(L.ocean_mfa_fwd_workspace(ctypes.byref(sh)), device=t.device, dtype=torch.float32)
+        out = torch.empty(sh.B, sh.W, device=t.device, dtype=torch.float32)
+        _hip.check(L.ocean_mfa_fwd(ctypes.byref(sh), _hip.dev_ptr(t, "temporal"), _hip.dev_ptr(s, "spatial"),
+                                   _hip.dev_ptr(l, "logs"), _hip.ptr_table(params, "mfa param"), _hip.dev_ptr(ws), ws.numel(),
+                                   _hip.dev_ptr(out), _hip.stream()), "ocean_mfa_fwd")
+        ctx.sh = sh
+        ctx.save_for_backward(t, s, l, ws, *params)
+        module._last_ws = ws if module._keep_ws else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _hip.lib()
+        t, s, l, ws, *params = ctx.saved_tensors
+        sh = ctx.sh
+        wb = torch.empty(L.ocean_mfa_bwd_workspace(ctypes.byref(sh)), device=t.device, dtype=torch.float32)
+        grads = [torch.zeros_like(p) for p in params]
+        dt = torch.empty_like(t) if ctx.needs_input_grad[0] else None
+        ds = torch.empty_like(s) if ctx.needs_input_grad[1] else None
+        dl = torch.empty_like(l) if ctx.needs_input_grad[2] else None
+        _hip.check(L.ocean_mfa_bwd(ctypes.byref(sh), _hip.dev_ptr(t), _hip.dev_ptr(s), _hip.dev_ptr(l),
+                                   _hip.ptr_table(params, "mfa param"), _hip.dev_ptr(ws), _hip.dev_ptr(wb), wb.numel(),
+                                   _hip.dev_ptr(dout.contiguous(), "grad_output"), _hip.ptr_table(grads, "mfa grad"),
+                                   _hip.dev_ptr(dt), _hip.dev_ptr(ds), _hip.dev_ptr(dl), _hip.stream()), "ocean_mfa_bwd")
+        return (dt, ds, dl, None) + tuple(g if ctx.needs_input_grad[4 + i] else None for i, g in enumerate(grads))
+
+
+class MultiFactorAttention(nn.Module):
+    def __init__(self, temporal_dim: int, spatial_dim: int, log_dim: int, attention_dim: int = 128, num_heads: int = 8,
+                 dropout: float = 0.1, fusion_strategy: str = "concatenate"):
+        super().__init__()
+        self.temporal_dim, self.spatial_dim, self.log_dim = temporal_dim, spatial_dim, log_dim
+        self.attention_dim, self.num_heads, self.fusion_strategy = attention_dim, num_heads, fusion_strategy
+        d = attention_dim
+        self.temporal_projection = nn.Linear(temporal_dim, d)
+        self.spatial_projection = nn.Linear(spatial_dim, d)
+        self.log_projection = nn.Linear(log_dim, d)
+        self.temporal_self_attention = MultiHeadAttention(d, num_heads, dropout)
+        self.spatial_self_attention = MultiHeadAttention(d, num_heads, dropout)
+        self.log_self_attention = MultiHeadAttention(d, num_heads, dropout)
+        self.temporal_spatial_attention = CrossModalAttention(d, num_heads, dropout)
+        self.temporal_log_attention = CrossModalAttention(d, num_heads, dropout)
+        self.spatial_log_attention = CrossModalAttention(d, num_heads, dropout)
+        self.modality_weights = nn.Parameter(torch.ones(3))
+        self.feature_attention = nn.Sequential(nn.Linear(d, d // 2), nn.ReLU(), nn.Linear(d // 2, 1), nn.Sigmoid())
+        if fusion_strategy == "concatenate":
+            self.fusion_dim = d * 3
+            self.fusion_layer = nn.Linear(self.fusion_dim, d)
+        elif fusion_strategy == "add":
+            self.fusion_dim = d
+            self.fusion_layer = nn.Identity()
+        elif fusion_strategy == "gate":
+            self.fusion_dim = d
+            self.gate_layer = nn.Sequential(nn.Linear(d * 3, d), nn.Sigmoid())
+        self.output_projection = nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Dropout(dropout), nn.Linear(d, d))
+        self.layer_norms = nn.ModuleDict({k: nn.LayerNorm(d) for k in ("temporal", "spatial", "log", "output")})
+        self._keep_ws, self._last_ws = False, None
+
+    def _param_list(self):
+        ps = []
+        for proj in (self.temporal_projection, self.spatial_projection, self.log_projection):
+            ps += [proj.weight, proj.bias]
+        for att in (self.temporal_self_attention, self.spatial_self_attention, self.log_self_attention):
+            ps += [att.w_v.weight, att.w_v.bias, att.w_o.weight, att.w_o.bias]
+        for k in ("temporal", "spatial", "log", "output"):
+            ps += [self.layer_norms[k].weight, self.layer_norms[k].bias]
+        ps.append(self.modality_weights)
+        fa, op = self.feature_attention, self.output_projection
+        ps += [fa[0].weight, fa[0].bias, fa[2].weight, fa[2].bias, self.fusion_layer.weight, self.fusion_layer.bias,
+               op[0].weight, op[0].bias, op[3].weight, op[3].bias]
+        return ps
+
+    def _shape(self, t, s, l) -> _hip.MfaShape:
+        sh = _hip.MfaShape()
+        sh.B, sh.td, sh.sd, sh.ld = t.shape[0], t.shape[1], s.shape[1], l.shape[1]
+        sh.W, sh.heads, sh.training = self.attention_dim, self.num_heads, int(self.training)
+        sh.dropout = float(self.output_projection[2].p) if self.training else 0.0
+        sh.eps = self.layer_norms["output"].eps
+        sh.seed = _hip.new_seed(sh.dropout)
+        return sh
+
+    def forward(self, temporal_features: torch.Tensor, spatial_features: torch.Tensor, log_features: torch.Tensor,
+                return_attention_weights: bool = False):
+        if self.fusion_strategy != "concatenate":
+            raise NotImplementedError("the HIP path implements fusion_strategy='concatenate' (the one OCEANModel uses)")
+        t, s, l = (x.contiguous().float() for x in (temporal_features, spatial_features, log_features))
+        if not (t.shape[0] == s.shape[0] == l.shape[0]):
+            raise ValueError("temporal, spatial and log features must share the batch dimension")
+        if (t.shape[1], s.shape[1], l.shape[1]) != (self.temporal_dim, self.spatial_dim, self.log_dim):
+            raise ValueError("feature widths do not match the module's temporal/spatial/log dims")
+        self._keep_ws = return_attention_weights
+        out = _MfaFunction.apply(t, s, l, self, *self._param_list())
+        if not return_attention_weights:
+            return out
+        B = t.shape[0]
+        gates = self._gates(self._last_ws, B)
+        self._keep_ws, self._last_ws = False, None
+        info = {"modality_weights": torch.softmax(self.modality_weights.detach(), dim=0),
+                "feature_importance": {k: gates[i].unsqueeze(1) for i, k in enumerate(("temporal", "spatial", "log"))},
+                "self_attention": {k: torch.ones(B, self.num_heads, 1, 1, device=out.device)
+                                   for k in ("temporal", "spatial", "log")}}
+        return out, info
+
+    def _gates(self, ws, B):
+        # the sigmoid feature gates live in the forward workspace right after the hidden layer of feature_attention
+        W, al4 = self.attention_dim, lambda n: (n + 3) // 4 * 4
+        off = 3 * al4(3 * B * W) + al4(6 * B) + al4(3 * B * W) + al4(6 * B) + al4(3 * B * W) + al4(3 * B * (W // 2))
+        return ws[off: off + 3 * B].view(3, B).clone()
+
+    def get_attention_analysis(self, temporal_features, spatial_features, log_features) -> Dict[str, Any]:
+        with torch.no_grad():
+            _, info = self.forward(temporal_features, spatial_features, log_features, return_attention_weights=True)
+        mw = info["modality_weights"].cpu()
+        return {"modality_importance": {"temporal": mw[0].item(), "spatial": mw[1].item(), "log": mw[2].item()},
+                "feature_importance": {k: v.mean().item() for k, v in info["feature_importance"].items()}}
+
+    def get_model_info(self) -> Dict[str, Any]:
+        total = sum(p.numel() for p in self.parameters())
+        return {"model_type": "MultiFactorAttention", "temporal_dim": self.temporal_dim, "spatial_dim": self.spatial_dim,
+                "log_dim": self.log_dim, "attention_dim": self.attention_dim, "num_heads": self.num_heads,
+                "fusion_strategy": self.fusion_strategy, "total_parameters": total,
+                "trainable_parameters": sum(p.numel() for p in self.parameters() if p.requires_grad)}

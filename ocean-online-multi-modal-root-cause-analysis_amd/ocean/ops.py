@@ -1,0 +1,91 @@
+"""Autograd wrappers over single C-ABI entry points (losses and small glue).
+
+Each function validates shapes on the host, allocates outputs / workspaces
+through torch's caching allocator and enqueues the HIP work on the current
+stream.  None of them has a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _hip
+
+
+class _InfoNce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, positive, negatives, tau, label_offset, mean_rows):
+        L = _hip.lib()
+        sh = _hip.InfoNceShape()
+        sh.B, sh.P = anchor.shape
+        sh.Bp = positive.shape[0]
+        sh.K = 0 if negatives is None else negatives.shape[0]
+        sh.label_offset, sh.mean_rows, sh.tau = label_offset, mean_rows, tau
+        ws = torch.empty(L.ocean_infonce_workspace(ctypes.byref(sh)), device=anchor.device, dtype=torch.float32)
+        loss = torch.zeros((), device=anchor.device, dtype=torch.float32)
+        _hip.check(L.ocean_infonce_fwd(ctypes.byref(sh), _hip.dev_ptr(anchor, "anchor"), _hip.dev_ptr(positive, "positive"),
+                                       _hip.dev_ptr(negatives, "negatives"), _hip.dev_ptr(ws), ws.numel(), _hip.dev_ptr(loss),
+                                       _hip.stream()), "ocean_infonce_fwd")
+        ctx.sh = sh
+        ctx.save_for_backward(anchor, positive, ws)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        L = _hip.lib()
+        anchor, positive, ws = ctx.saved_tensors
+        sh = ctx.sh
+        wb = torch.empty(L.ocean_infonce_bwd_workspace(ctypes.byref(sh)), device=anchor.device, dtype=torch.float32)
+        da, dp = torch.empty_like(anchor), torch.empty_like(positive)
+        _hip.check(L.ocean_infonce_bwd(ctypes.byref(sh), _hip.dev_ptr(anchor), _hip.dev_ptr(positive), _hip.dev_ptr(ws),
+                                       _hip.dev_ptr(wb), wb.numel(), _hip.dev_ptr(dloss.contiguous().float(), "dloss"),
+                                       _hip.dev_ptr(da), _hip.dev_ptr(dp), _hip.stream()), "ocean_infonce_bwd")
+        return da, dp, None, None, None, None
+
+
+def infonce(anchor: torch.Tensor, positive: torch.Tensor, negatives: Optional[torch.Tensor] = None,
+            temperature: float = 0.1, label_offset: int = 0, mean_rows: int = 0) -> torch.Tensor:
+    """InfoNCELoss.forward (graph_fusion.py:112-162), reduction='mean'.
+    negatives given: memory-bank branch; None: in-batch branch where row b of
+    `anchor` is matched with row label_offset + b of `positive`."""
+    if anchor.dim() != 2 or positive.dim() != 2 or anchor.shape[1] != positive.shape[1]:
+        raise ValueError("anchor and positive must be [B, dim] with equal dim")
+    if negatives is not None:
+        if positive.shape[0] != anchor.shape[0]:
+            raise ValueError("anchor and positive must have the same batch size")
+        negatives = negatives.detach().contiguous().float()
+    return _InfoNce.apply(anchor.contiguous().float(), positive.contiguous().float(), negatives, float(temperature),
+                          int(label_offset), int(mean_rows))
+
+
+class _Bce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probs, targets, mean_n):
+        loss = torch.zeros((), device=probs.device, dtype=torch.float32)
+        _hip.check(_hip.lib().ocean_bce_fwd(_hip.dev_ptr(probs, "probs"), _hip.dev_ptr(targets, "targets"), probs.numel(),
+                                            mean_n, _hip.dev_ptr(loss), _hip.stream()), "ocean_bce_fwd")
+        ctx.mean_n = mean_n
+        ctx.save_for_backward(probs, targets)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        probs, targets = ctx.saved_tensors
+        dp = torch.empty_like(probs)
+        _hip.check(_hip.lib().ocean_bce_bwd(_hip.dev_ptr(probs), _hip.dev_ptr(targets), _hip.dev_ptr(dloss.contiguous().float()),
+                                            probs.numel(), ctx.mean_n, _hip.dev_ptr(dp), _hip.stream()), "ocean_bce_bwd")
+        return dp, None, None
+
+
+def binary_cross_entropy(probs: torch.Tensor, targets: torch.Tensor, reduction: str = "mean") -> torch.Tensor:
+    """F.binary_cross_entropy on probabilities (ocean_model.py:249-253), log terms clamped at -100."""
+    if probs.shape != targets.shape:
+        raise ValueError(f"Using a target size ({tuple(targets.shape)}) that is different to the input size "
+                         f"({tuple(probs.shape)}) is deprecated. Please ensure they have the same size.")
+    if reduction not in ("mean", "sum"):
+        raise NotImplementedError("reduction must be 'mean' or 'sum'")
+    loss = _Bce.apply(probs.contiguous().float(), targets.to(probs.device).contiguous().float(),
+                      0 if reduction == "mean" else 1)
+    return loss
