@@ -43,6 +43,10 @@ int ocean_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, i
                    int M, int N, int K, int a_kmajor, int b_kn,
                    const float* bias, const float* R, int ldr, int relu, void* stream);
 
+/* out[G,C] = mean over the middle axis of a[G,n,C].  Replaces torch.mean(logs, dim=1) for
+ * [B,L,768] log embeddings (ocean/models/ocean_model.py:179-181). */
+int ocean_mean_mid_f32(const float* a, float* out, int G, int n, int C, void* stream);
+
 /* ------------------------------------------------------------------ DilatedCNN
  * Replaces DilatedCNN.forward / DilatedConvBlock.forward
  * (ocean/models/components/dilated_cnn.py:76-99, 195-241) and their autograd

@@ -16,4 +16,10 @@ int ocean_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, i
   return ocean_launch_gemm(p, (hipStream_t)stream);
 }
 
+int ocean_mean_mid_f32(const float* a, float* out, int G, int n, int C, void* stream) {
+  if (!a || !out) return OCEAN_ERR_NULL;
+  if (G <= 0 || n <= 0 || C <= 0) return OCEAN_ERR_BAD_SHAPE;
+  return mean_mid(a, out, G, n, C, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -1,0 +1,293 @@
+"""Online learner: per-sample / per-batch update steps on MI355X.
+
+Same classes, constructor arguments, return dictionaries and checkpoint
+layout as the reference (ocean/models/training/online_learner.py:26-580).
+The update arithmetic - forward, loss, backward, clip_grad_norm_(1.0), Adam -
+runs in HIP kernels; the buffers and the learning-rate policy are host logic
+reproduced as they are.  One device->host read per step (the three loss
+scalars at once) replaces the reference's 3-6 .item() calls.
+"""
+from __future__ import annotations
+
+import logging
+import queue
+import threading
+from collections import defaultdict, deque
+from datetime import datetime, timedelta
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ...configs import OCEANConfig
+from ...data.data_types import DatasetSample
+from ...optim import FusedAdam
+from ..ocean_model import OCEANModel
+
+logger = logging.getLogger(__name__)
+
+
+class MemoryBuffer:
+    """Bounded store of recent samples with an importance score each
+    (online_learner.py:26-127): 'fifo', 'random' or 'importance' eviction;
+    importance-weighted sampling without replacement."""
+
+    def __init__(self, max_size: int = 1000, retention_strategy: str = "fifo"):
+        self.max_size, self.retention_strategy = max_size, retention_strategy
+        self.buffer: deque = deque(maxlen=max_size)
+        self.importance_scores: deque = deque(maxlen=max_size)
+        self.timestamps: deque = deque(maxlen=max_size)
+
+    def add(self, sample: DatasetSample, importance_score: float = 1.0):
+        if len(self.buffer) >= self.max_size:
+            self._remove_sample()
+        self.buffer.append(sample)
+        self.importance_scores.append(importance_score)
+        self.timestamps.append(datetime.now())
+
+    def _drop_at(self, idx: int):
+        for name in ("buffer", "importance_scores", "timestamps"):
+            items = list(getattr(self, name))
+            items.pop(idx)
+            setattr(self, name, deque(items, maxlen=self.max_size))
+
+    def _remove_sample(self):
+        if self.retention_strategy == "fifo":
+            # the sample deque evicts its own oldest entry on append
+            self.importance_scores.popleft()
+            self.timestamps.popleft()
+        elif self.retention_strategy == "random" and len(self.buffer) > 0:
+            self._drop_at(int(np.random.randint(0, len(self.buffer))))
+        elif self.retention_strategy == "importance" and len(self.importance_scores) > 0:
+            self._drop_at(int(np.argmin(list(self.importance_scores))))
+
+    def sample(self, batch_size: int) -> List[DatasetSample]:
+        n = len(self.buffer)
+        if n == 0:
+            return []
+        if batch_size >= n:
+            return list(self.buffer)
+        if self.retention_strategy == "importance":
+            w = np.array(list(self.importance_scores))
+            idx = np.random.choice(n, size=batch_size, replace=False, p=w / w.sum())
+        else:
+            idx = np.random.choice(n, size=batch_size, replace=False)
+        return [self.buffer[i] for i in idx]
+
+    def get_recent(self, time_window: timedelta) -> List[DatasetSample]:
+        cutoff = datetime.now() - time_window
+        return [s for s, t in zip(self.buffer, self.timestamps) if t >= cutoff]
+
+    def __len__(self):
+        return len(self.buffer)
+
+
+class SlidingWindow:
+    def __init__(self, window_size: int, step_size: int = 1):
+        self.window_size, self.step_size = window_size, step_size
+        self.window: deque = deque(maxlen=window_size)
+        self.step_counter = 0
+
+    def add(self, sample: DatasetSample) -> bool:
+        self.window.append(sample)
+        self.step_counter += 1
+        return len(self.window) == self.window_size and self.step_counter % self.step_size == 0
+
+    def get_window(self) -> List[DatasetSample]:
+        return list(self.window)
+
+    def reset(self):
+        self.window.clear()
+        self.step_counter = 0
+
+
+class AdaptiveLearningRateScheduler:
+    """Decay lr by `decay_factor` whenever, over a full window of losses, the
+    newer half's mean is not below the older half's (online_learner.py:200-227)."""
+
+    def __init__(self, initial_lr: float = 0.001, decay_factor: float = 0.95, adaptation_window: int = 100,
+                 min_lr: float = 1e-6):
+        self.initial_lr = self.current_lr = initial_lr
+        self.decay_factor, self.adaptation_window, self.min_lr = decay_factor, adaptation_window, min_lr
+        self.performance_history: deque = deque(maxlen=adaptation_window)
+        self.lr_history: List[float] = []
+
+    def step(self, performance_metric: float, optimizer: optim.Optimizer) -> float:
+        self.performance_history.append(performance_metric)
+        if len(self.performance_history) >= self.adaptation_window:
+            hist, half = list(self.performance_history), self.adaptation_window // 2
+            if np.mean(hist[-half:]) >= np.mean(hist[:half]):
+                self.current_lr = max(self.current_lr * self.decay_factor, self.min_lr)
+                for group in optimizer.param_groups:
+                    group["lr"] = self.current_lr
+        self.lr_history.append(self.current_lr)
+        return self.current_lr
+
+    def reset(self):
+        self.current_lr = self.initial_lr
+        self.performance_history.clear()
+
+
+class OnlineLearner:
+    def __init__(self, model: OCEANModel, config: OCEANConfig, optimizer: Optional[optim.Optimizer] = None):
+        self.model, self.config = model, config
+        self.optimizer = optimizer if optimizer is not None else FusedAdam(
+            model.parameters(), lr=config.training.learning_rate, weight_decay=config.training.weight_decay)
+        self.memory_buffer = MemoryBuffer(max_size=config.training.sliding_window_size, retention_strategy="importance")
+        self.sliding_window = SlidingWindow(window_size=getattr(config.data, "sequence_length", 100),
+                                            step_size=config.training.update_frequency)
+        self.lr_scheduler = AdaptiveLearningRateScheduler(initial_lr=config.training.learning_rate)
+        self.performance_history = defaultdict(list)
+        self.update_count = 0
+        self.last_update_time = datetime.now()
+        self.data_queue: queue.Queue = queue.Queue(maxsize=1000)
+        self.is_streaming = False
+        self.stream_thread: Optional[threading.Thread] = None
+        # data-parallel hook: called with the list of parameters after backward, before the update
+        self.grad_sync = None
+
+    # ------------------------------------------------------------------ the update step
+    def _losses_to_host(self, losses: Dict[str, Any]) -> Dict[str, float]:
+        """total / prediction / contrastive loss values with one device read."""
+        keys = [k for k in ("total_loss", "prediction_loss", "contrastive_loss") if torch.is_tensor(losses.get(k))]
+        vals = torch.stack([losses[k].detach().float().reshape(()) for k in keys]).cpu().tolist() if keys else []
+        out = dict(zip(keys, vals))
+        for k in ("total_loss", "prediction_loss", "contrastive_loss"):
+            if k in losses and k not in out:
+                out[k] = float(losses[k])
+        return out
+
+    def _apply_update(self, total_loss: torch.Tensor) -> None:
+        self.optimizer.zero_grad()
+        total_loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync(self.model)
+        clip = self.config.training.gradient_clip_norm
+        if isinstance(self.optimizer, FusedAdam):
+            self.optimizer.step(max_norm=clip if clip > 0 else 0.0)
+        else:
+            if clip > 0:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
+            self.optimizer.step()
+        self.update_count += 1
+
+    def process_sample(self, sample: DatasetSample, update_model: bool = True) -> Dict[str, float]:
+        self.model.train()
+        outputs = self.model(sample.metrics.unsqueeze(0), sample.graph, sample.logs.unsqueeze(0))
+        losses = self.model.compute_loss(outputs, sample.label.unsqueeze(0))
+        if update_model:
+            self._apply_update(losses["total_loss"])
+        host = self._losses_to_host(losses)
+        importance_score = host["total_loss"]
+        self.memory_buffer.add(sample, importance_score)
+        if update_model:
+            current_lr = self.lr_scheduler.step(host["total_loss"], self.optimizer)
+            self.performance_history["loss"].append(host["total_loss"])
+            self.performance_history["learning_rate"].append(current_lr)
+        results = {"loss": host["total_loss"], "prediction_loss": host["prediction_loss"],
+                   "importance_score": importance_score, "memory_buffer_size": len(self.memory_buffer),
+                   "update_count": self.update_count}
+        if "contrastive_loss" in host:
+            results["contrastive_loss"] = host["contrastive_loss"]
+        return results
+
+    def process_batch(self, batch_samples: List[DatasetSample]) -> Dict[str, float]:
+        if not batch_samples:
+            return {}
+        self.model.train()
+        service_graph = batch_samples[0].graph          # one graph for the batch (online_learner.py:382-383)
+        metrics = torch.stack([s.metrics for s in batch_samples])
+        logs = torch.stack([s.logs for s in batch_samples])
+        labels = torch.stack([s.label for s in batch_samples])
+        outputs = self.model(metrics, service_graph, logs)
+        losses = self.model.compute_loss(outputs, labels)
+        self._apply_update(losses["total_loss"])
+        host = self._losses_to_host(losses)
+        current_lr = self.lr_scheduler.step(host["total_loss"], self.optimizer)
+        self.performance_history["batch_loss"].append(host["total_loss"])
+        self.performance_history["learning_rate"].append(current_lr)
+        return {"batch_loss": host["total_loss"], "batch_prediction_loss": host["prediction_loss"],
+                "batch_size": len(batch_samples), "learning_rate": current_lr, "update_count": self.update_count}
+
+    def experience_replay(self, replay_batch_size: int = 32) -> Optional[Dict[str, float]]:
+        if len(self.memory_buffer) < replay_batch_size:
+            return None
+        results = self.process_batch(self.memory_buffer.sample(replay_batch_size))
+        results["replay"] = True
+        return results
+
+    # ------------------------------------------------------------------ streaming thread
+    def start_streaming(self):
+        if self.is_streaming:
+            logger.warning("Streaming already active")
+            return
+        self.is_streaming = True
+        self.stream_thread = threading.Thread(target=self._streaming_worker, daemon=True)
+        self.stream_thread.start()
+
+    def stop_streaming(self):
+        self.is_streaming = False
+        if self.stream_thread:
+            self.stream_thread.join(timeout=5.0)
+
+    def add_streaming_sample(self, sample: DatasetSample):
+        try:
+            self.data_queue.put(sample, timeout=1.0)
+        except queue.Full:
+            logger.warning("Streaming queue full, dropping sample")
+
+    def _streaming_worker(self):
+        while self.is_streaming:
+            try:
+                sample = self.data_queue.get(timeout=1.0)
+                results = self.process_sample(sample, update_model=True)
+                if self.update_count % self.config.training.update_frequency == 0:
+                    replay = self.experience_replay()
+                    if replay:
+                        logger.debug("Experience replay: %s", replay)
+                if self.update_count % 100 == 0:
+                    logger.info("Processed %d samples, current loss: %.4f", self.update_count, results["loss"])
+            except queue.Empty:
+                continue
+            except Exception as e:          # keep the worker alive, as the reference does
+                logger.error("Error in streaming worker: %s", e)
+
+    # ------------------------------------------------------------------ bookkeeping
+    def get_performance_summary(self) -> Dict[str, Any]:
+        summary = {"total_updates": self.update_count, "memory_buffer_size": len(self.memory_buffer),
+                   "is_streaming": self.is_streaming, "queue_size": self.data_queue.qsize(),
+                   "current_lr": self.lr_scheduler.current_lr}
+        for metric, values in self.performance_history.items():
+            if values:
+                summary[f"{metric}_mean"] = np.mean(values[-100:])
+                summary[f"{metric}_std"] = np.std(values[-100:])
+                summary[f"{metric}_trend"] = np.polyfit(range(len(values[-50:])), values[-50:], 1)[0] if len(values) >= 50 else 0
+        return summary
+
+    def save_checkpoint(self, filepath: str):
+        torch.save({"model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
+                    "update_count": self.update_count, "performance_history": dict(self.performance_history),
+                    "lr_scheduler_state": {"current_lr": self.lr_scheduler.current_lr,
+                                           "performance_history": list(self.lr_scheduler.performance_history),
+                                           "lr_history": self.lr_scheduler.lr_history}}, filepath)
+
+    def load_checkpoint(self, filepath: str):
+        ckpt = torch.load(filepath, map_location=self.model.device, weights_only=False)
+        self.model.load_state_dict(ckpt["model_state_dict"])
+        self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+        self.update_count = ckpt["update_count"]
+        for metric, values in ckpt["performance_history"].items():
+            self.performance_history[metric] = values
+        st = ckpt.get("lr_scheduler_state")
+        if st:
+            self.lr_scheduler.current_lr = st["current_lr"]
+            self.lr_scheduler.performance_history = deque(st["performance_history"], maxlen=self.lr_scheduler.adaptation_window)
+            self.lr_scheduler.lr_history = st["lr_history"]
+
+    def reset(self):
+        self.memory_buffer = MemoryBuffer(max_size=self.config.training.sliding_window_size, retention_strategy="importance")
+        self.sliding_window.reset()
+        self.lr_scheduler.reset()
+        self.performance_history.clear()
+        self.update_count = 0

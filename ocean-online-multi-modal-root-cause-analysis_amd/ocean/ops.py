@@ -89,3 +89,16 @@ def binary_cross_entropy(probs: torch.Tensor, targets: torch.Tensor, reduction: 
     loss = _Bce.apply(probs.contiguous().float(), targets.to(probs.device).contiguous().float(),
                       0 if reduction == "mean" else 1)
     return loss
+
+
+def mean_tokens(x: torch.Tensor) -> torch.Tensor:
+    """[B,L,C] -> [B,C] mean over L (log-embedding sequences, ocean_model.py:179-181).  Inputs only: no gradient."""
+    if x.dim() != 3:
+        raise ValueError("expected [batch, tokens, dim]")
+    if x.requires_grad:
+        raise NotImplementedError("mean_tokens is applied to model inputs and carries no gradient")
+    x = x.contiguous().float()
+    out = torch.empty(x.shape[0], x.shape[2], device=x.device, dtype=torch.float32)
+    _hip.check(_hip.lib().ocean_mean_mid_f32(_hip.dev_ptr(x, "logs"), _hip.dev_ptr(out), x.shape[0], x.shape[1], x.shape[2],
+                                             _hip.stream()), "ocean_mean_mid_f32")
+    return out

@@ -1,0 +1,97 @@
+"""Fused gradient clipping + Adam for the online update step.
+
+Drop-in for the pair the reference uses at
+ocean/models/training/online_learner.py:325-335 / 402-412:
+``clip_grad_norm_(params, max_norm)`` followed by ``torch.optim.Adam.step()``
+(Adam built at :256-261: lr, betas (0.9, 0.999), eps 1e-8, coupled L2
+weight_decay).  State keys match torch.optim.Adam ('step', 'exp_avg',
+'exp_avg_sq') so checkpoints interchange.  Parameters whose .grad is None
+are skipped and keep no state, exactly like torch.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _hip
+
+_CHUNK = 16384
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._table_key = None
+        self._table = None
+        self._n_chunks = 0
+        self._sq = None
+        self.last_grad_norm: Optional[torch.Tensor] = None      # device scalar, set when max_norm is given
+
+    def _build_table(self, entries, device):
+        rows = []
+        for p, g, m, v in entries:
+            n, base = p.numel(), 0
+            while base < n:
+                c = min(_CHUNK, n - base)
+                rows.append((p.data_ptr() + 4 * base, g.data_ptr() + 4 * base, m.data_ptr() + 4 * base, v.data_ptr() + 4 * base, c))
+                base += c
+        t = torch.tensor(rows, dtype=torch.int64).to(device, non_blocking=True)   # 5 x int64 per row == ocean_adam_chunk
+        return t, len(rows)
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm: float = 0.0, write_clipped: bool = True):
+        """One Adam update.  max_norm > 0 first scales every gradient by
+        min(1, max_norm / (global_norm + 1e-6)) like clip_grad_norm_."""
+        loss = closure() if closure is not None else None
+        L = _hip.lib()
+        for group in self.param_groups:
+            by_step = {}
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+                    raise _hip.OceanHipError("FusedAdam needs contiguous fp32 parameters and gradients on the GPU")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                by_step.setdefault(int(st["step"]), []).append((p, p.grad, st["exp_avg"], st["exp_avg_sq"]))
+            if not by_step:
+                continue
+            device = next(iter(by_step.values()))[0][0].device
+            all_entries = [e for k in sorted(by_step) for e in by_step[k]]
+            key = tuple((e[0].data_ptr(), e[1].data_ptr(), e[2].data_ptr()) for e in all_entries) + tuple(
+                (k, len(v)) for k, v in sorted(by_step.items()))
+            if key != self._table_key:
+                self._table, self._n_chunks = self._build_table(all_entries, device)
+                self._table_key = key
+                # chunk ranges per distinct step count (normally one)
+                self._ranges, pos = [], 0
+                for k in sorted(by_step):
+                    n = sum((e[0].numel() + _CHUNK - 1) // _CHUNK for e in by_step[k])
+                    self._ranges.append((pos, n))
+                    pos += n
+            sq_ptr = ctypes.c_void_p(0)
+            if max_norm and max_norm > 0:
+                if self._sq is None or self._sq.device != device:
+                    self._sq = torch.zeros(1, dtype=torch.float64, device=device)
+                self._sq.zero_()
+                _hip.check(L.ocean_grad_sqnorm(ctypes.c_void_p(self._table.data_ptr()), self._n_chunks,
+                                               ctypes.c_void_p(self._sq.data_ptr()), _hip.stream()), "ocean_grad_sqnorm")
+                sq_ptr = ctypes.c_void_p(self._sq.data_ptr())
+                self.last_grad_norm = self._sq
+            b1, b2 = group["betas"]
+            for (pos, n), k in zip(self._ranges, sorted(by_step)):
+                _hip.check(L.ocean_clip_adam_step(ctypes.c_void_p(self._table.data_ptr() + 40 * pos), n, sq_ptr, float(max_norm or 0.0),
+                                                  float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                  float(group["weight_decay"]), int(k), int(write_clipped), _hip.stream()),
+                           "ocean_clip_adam_step")
+        return loss
+
+    def grad_norm(self) -> Optional[torch.Tensor]:
+        """sqrt of the squared norm accumulated by the last clipped step (device tensor)."""
+        return None if self.last_grad_norm is None else self.last_grad_norm.sqrt().float()
