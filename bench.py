@@ -1,0 +1,172 @@
+"""Headline benchmark: samples/sec of the OCEAN fwd+bwd online step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one online update of OCEANModel on one batch resident in HBM:
+forward, compute_loss (BCE + 0.1 * 3 in-batch InfoNCE), backward,
+clip_grad_norm_(1.0), Adam - what OnlineLearner.process_batch runs, including
+its one loss read-back per step.  Workload (BASELINE.json configs[2]): 256
+services (directed Erdos-Renyi graph, mean in-degree 8), seq_len 128, 12
+metric features, 768-d log embeddings, batch 1024 PER GPU (weak scaling),
+reference default hyper-parameters (dropout 0.1 everywhere, so every graph
+replica is computed), fp32.
+
+For N > 1 launch with torch.distributed.run; ranks are data-parallel (RCCL):
+flat gradient all-reduce, all-reduced BatchNorm statistics, all-gathered
+InfoNCE positives.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ocean-online-multi-modal-root-cause-analysis_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_inputs(B, T, N, S, rank, device):
+    g = lambda s: torch.Generator().manual_seed(s)
+    metrics = torch.randn(B, T, 12, generator=g(1000 + rank))
+    logs = torch.randn(B, 768, generator=g(2000 + rank))
+    nf = torch.randn(N, 12, generator=g(7))
+    adj = (torch.rand(N, N, generator=g(11)) < 8.0 / N).float()
+    adj.fill_diagonal_(0.0)
+    labels = torch.zeros(B, S)
+    labels[torch.arange(B), torch.randint(0, S, (B,), generator=g(3000 + rank))] = 1.0
+    return metrics.to(device), logs.to(device), nf, adj, labels.to(device)
+
+
+def cpu_baseline(model, nf, adj, T, S, budget_s=25.0):
+    """The CPU oracle's update step (PyTorch CPU eager, fp32) on a bounded batch, timed with the recipe of
+    the reference's profiler (3 warm-up + timed iterations, perf_counter)."""
+    from oracle import ocean_ref as R
+    Bc = 32
+    sd = R.require_grad({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    g = lambda s: torch.Generator().manual_seed(s)
+    metrics, logs = torch.randn(Bc, T, 12, generator=g(1)), torch.randn(Bc, 768, generator=g(2))
+    labels = torch.zeros(Bc, S)
+    labels[torch.arange(Bc), torch.randint(0, S, (Bc,), generator=g(3))] = 1.0
+    tk = [k for k in R.trainable_keys(sd) if sd[k].is_floating_point()]
+    state = {k: {} for k in tk}
+
+    def step():
+        for k in tk:
+            sd[k].grad = None
+        out = R.model_forward(sd, metrics, adj, nf, logs, training=True, negatives="in_batch")
+        R.compute_loss(out, labels)["total_loss"].backward()
+        wg = [k for k in tk if sd[k].grad is not None]
+        R.clip_grad_norm([sd[k].grad for k in wg], 1.0)
+        with torch.no_grad():
+            R.adam_step([sd[k] for k in wg], [sd[k].grad for k in wg], [state[k] for k in wg])
+
+    for _ in range(2):
+        step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 10 and time.perf_counter() - t0 < budget_s:
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": Bc / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} update steps of batch {Bc} (same graph, T={T}, S={S}, in-batch InfoNCE; dropout off and one graph "
+                      f"replica computed and broadcast, i.e. less work than the GPU step), {dt * 1e3:.0f} ms/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch")
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--services", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    import ocean
+    from ocean import _hip
+    from ocean.data import ServiceGraph
+    from ocean.models.training import OnlineLearner
+
+    B, T, N = args.batch, args.seq_len, args.services
+    cfg = ocean.default_config()
+    cfg.model.num_services = N
+    torch.manual_seed(42)
+    model = ocean.OCEANModel(cfg).to(device)
+    model.contrastive_negatives = "in_batch"
+    learner = OnlineLearner(model, cfg)
+    if world > 1:
+        from ocean.parallel import DataParallel
+        DataParallel(model, learner)
+    metrics, logs, nf, adj, labels = synth_inputs(B, T, N, N, rank, device)
+    graph = ServiceGraph(adjacency_matrix=adj, node_features=nf)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        learner.process_tensors(metrics, graph, logs, labels)
+    barrier()
+    _hip.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        learner.process_tensors(metrics, graph, logs, labels)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = _hip.profile_summary()
+    _hip.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        dom = max(prof, key=lambda r: r["total_ms"])
+        achieved = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        gemm_ms = sum(r["total_ms"] for r in prof) / args.steps
+        out = {
+            "metric": "samples/sec fwd+bwd online step (256 svc, seq 128)",
+            "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2] (C3): {N} services (ER graph, in-degree 8), batch {B} per GPU, seq_len {T}, "
+                                   "online update step = fwd + BCE/InfoNCE(in-batch) loss + bwd + clip(1.0) + Adam, "
+                                   "reference default hyper-parameters (dropout 0.1: every graph replica computed)",
+                       "global_batch": world * B, "seq_len": T, "services": N, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": dom["kernel"],
+                         "launches_per_step": dom["launches"] / args.steps,
+                         "avg_launch_ms": dom["total_ms"] / dom["launches"],
+                         "all_gemm_ms_per_step": gemm_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, nf, adj, T, N)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -242,6 +242,14 @@ int ocean_clip_adam_step(const ocean_adam_chunk* table, int n_chunks, const doub
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          int write_clipped, void* stream);
 
+/* ------------------------------------------------------------------ kernel timing (measurement aid)
+ * No counterpart in the reference.  While enabled, every GEMM launch is bracketed by HIP events on its
+ * stream (this is the one place the library creates runtime objects).  ocean_prof_summary waits for the
+ * recorded events and writes a JSON array, one object per kernel instantiation:
+ * {"kernel", "launches", "total_ms", "flops", "bytes"} (algorithmic flops / bytes summed over launches). */
+int ocean_prof_enable(int on);
+int ocean_prof_summary(char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

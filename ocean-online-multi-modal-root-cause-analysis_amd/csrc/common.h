@@ -80,6 +80,11 @@ struct GemmP {
 
 int ocean_launch_gemm(const GemmP& p, hipStream_t stream);
 
+// optional kernel timing (prof.hip); token is null while profiling is off
+bool ocean_prof_on();
+void ocean_prof_begin(const char* name, double flops, double bytes, hipStream_t s, void** token);
+void ocean_prof_end(void* token, hipStream_t s);
+
 static inline GemmP gemm_defaults() {
   GemmP p;
   p.A = p.B = nullptr; p.C = nullptr; p.M = p.N = p.K = 0; p.lda = p.ldb = p.ldc = 0;

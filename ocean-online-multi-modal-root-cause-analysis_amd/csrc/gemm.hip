@@ -17,6 +17,7 @@
 // Global loads for tile i+1 are issued before the MFMAs of tile i (register
 // prefetch) and written to the other LDS buffer afterwards: one barrier per tile.
 #include "common.h"
+#include <cstdio>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -284,8 +285,18 @@ template <int BM, int BN, int BK, bool AKM, bool BKN>
 int launch_cfg(const GemmP& p, bool aligned, hipStream_t stream) {
   const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
   dim3 grid(tiles, 1, AKM ? p.taps * (p.split_k > 0 ? p.split_k : 1) : 1);
+  void* tok = nullptr;
+  if (ocean_prof_on()) {
+    char name[96];
+    snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%d,%d,%s,%s,%s>", BM, BN, BK, AKM ? "true" : "false", BKN ? "true" : "false",
+             aligned ? "true" : "false");
+    const double flops = 2.0 * p.M * p.N * (double)p.K * p.taps;
+    const double bytes = 4.0 * ((double)p.M * p.K * (AKM ? 1 : 1) + (double)p.N * p.K * p.taps + (double)p.M * p.N * (AKM ? p.taps : 1));
+    ocean_prof_begin(name, flops, bytes, stream, &tok);
+  }
   if (aligned) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, true>), grid, dim3(kThreads), 0, stream, p);
   else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, false>), grid, dim3(kThreads), 0, stream, p);
+  ocean_prof_end(tok, stream);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }

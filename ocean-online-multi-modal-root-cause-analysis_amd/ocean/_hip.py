@@ -116,6 +116,8 @@ def _declare_rest(lib) -> None:
     sig("ocean_bce_fwd", c_int, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_bce_bwd", c_int, vp, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_mean_mid_f32", c_int, vp, vp, c_int, c_int, c_int, vp)
+    sig("ocean_prof_enable", c_int, c_int)
+    sig("ocean_prof_summary", c_int, ctypes.c_char_p, c_size_t)
     sig("ocean_grad_sqnorm", c_int, vp, c_int, vp, vp)
     sig("ocean_clip_adam_step", c_int, vp, c_int, vp, c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_int, vp)
 
@@ -195,3 +197,15 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
                               ldr or ldc, int(relu), stream())
     check(st, "ocean_gemm_f32")
     return out
+
+
+def profile_enable(on: bool) -> None:
+    check(lib().ocean_prof_enable(int(on)), "ocean_prof_enable")
+
+
+def profile_summary():
+    """Per-kernel totals of the GEMM launches recorded since profile_enable(True)."""
+    import json
+    buf = ctypes.create_string_buffer(1 << 16)
+    check(lib().ocean_prof_summary(buf, len(buf)), "ocean_prof_summary")
+    return json.loads(buf.value.decode())

@@ -67,8 +67,13 @@ class CrossModalAttention(nn.Module):
 
 class _MfaFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, t, s, l, module, *params):
+    def forward(ctx, t, s, l, module, n_live, *params):
+        # params[:n_live] feed the kernels; params[n_live:] are the w_q / w_k tensors of the three
+        # length-1 self-attentions: they cannot influence the output and get exact-zero gradients
+        # (the reference's autograd gives them zeros too, so its Adam still applies weight decay)
         L = _hip.lib()
+        ctx.dead = params[n_live:]
+        params = params[:n_live]
         sh = module._shape(t, s, l)
         ws = torch.empty(L.ocean_mfa_fwd_workspace(ctypes.byref(sh)), device=t.device, dtype=torch.float32)
         out = torch.empty(sh.B, sh.W, device=t.device, dtype=torch.float32)
@@ -94,7 +99,10 @@ class _MfaFunction(torch.autograd.Function):
                                    _hip.ptr_table(params, "mfa param"), _hip.dev_ptr(ws), _hip.dev_ptr(wb), wb.numel(),
                                    _hip.dev_ptr(dout.contiguous(), "grad_output"), _hip.ptr_table(grads, "mfa grad"),
                                    _hip.dev_ptr(dt), _hip.dev_ptr(ds), _hip.dev_ptr(dl), _hip.stream()), "ocean_mfa_bwd")
-        return (dt, ds, dl, None) + tuple(g if ctx.needs_input_grad[4 + i] else None for i, g in enumerate(grads))
+        live = tuple(g if ctx.needs_input_grad[5 + i] else None for i, g in enumerate(grads))
+        dead = tuple(torch.zeros_like(p) if ctx.needs_input_grad[5 + len(grads) + i] else None
+                     for i, p in enumerate(ctx.dead))
+        return (dt, ds, dl, None, None) + live + dead
 
 
 class MultiFactorAttention(nn.Module):
@@ -161,7 +169,11 @@ class MultiFactorAttention(nn.Module):
         if (t.shape[1], s.shape[1], l.shape[1]) != (self.temporal_dim, self.spatial_dim, self.log_dim):
             raise ValueError("feature widths do not match the module's temporal/spatial/log dims")
         self._keep_ws = return_attention_weights
-        out = _MfaFunction.apply(t, s, l, self, *self._param_list())
+        live = self._param_list()
+        dead = []
+        for att in (self.temporal_self_attention, self.spatial_self_attention, self.log_self_attention):
+            dead += [att.w_q.weight, att.w_q.bias, att.w_k.weight, att.w_k.bias]
+        out = _MfaFunction.apply(t, s, l, self, len(live), *live, *dead)
         if not return_attention_weights:
             return out
         B = t.shape[0]

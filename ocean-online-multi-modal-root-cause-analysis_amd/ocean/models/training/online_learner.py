@@ -200,15 +200,21 @@ class OnlineLearner:
         metrics = torch.stack([s.metrics for s in batch_samples])
         logs = torch.stack([s.logs for s in batch_samples])
         labels = torch.stack([s.label for s in batch_samples])
+        return self.process_tensors(metrics, service_graph, logs, labels)
+
+    def process_tensors(self, metrics: torch.Tensor, service_graph, logs: torch.Tensor, labels: torch.Tensor) -> Dict[str, float]:
+        """process_batch on already-collated tensors ([B,T,F], graph, [B,768], [B,S]); tensors that
+        already live on the model's device are used in place (no host staging)."""
+        self.model.train()
         outputs = self.model(metrics, service_graph, logs)
-        losses = self.model.compute_loss(outputs, labels)
+        losses = self.model.compute_loss(outputs, labels.to(self.model.device, non_blocking=True))
         self._apply_update(losses["total_loss"])
         host = self._losses_to_host(losses)
         current_lr = self.lr_scheduler.step(host["total_loss"], self.optimizer)
         self.performance_history["batch_loss"].append(host["total_loss"])
         self.performance_history["learning_rate"].append(current_lr)
         return {"batch_loss": host["total_loss"], "batch_prediction_loss": host["prediction_loss"],
-                "batch_size": len(batch_samples), "learning_rate": current_lr, "update_count": self.update_count}
+                "batch_size": int(metrics.shape[0]), "learning_rate": current_lr, "update_count": self.update_count}
 
     def experience_replay(self, replay_batch_size: int = 32) -> Optional[Dict[str, float]]:
         if len(self.memory_buffer) < replay_batch_size:
