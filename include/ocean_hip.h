@@ -225,6 +225,15 @@ int ocean_bce_fwd(const float* probs, const float* targets, long n, long mean_n,
 int ocean_bce_bwd(const float* probs, const float* targets, const float* dloss /* device scalar or NULL */,
                   long n, long mean_n, float* d_probs, void* stream);
 
+/* Extra terms of the Trainer's LossFunction (ocean/models/training/trainer.py:90-110):
+ * nn.MSELoss between two [n] tensors (gradient to `a` only), and the feature-diversity loss
+ * mean_{i != j} | normalize(x)_i . normalize(x)_j | over x [B,E].  *loss is ACCUMULATED. */
+int ocean_mse_fwd(const float* a, const float* b, long n, float* loss, void* stream);
+int ocean_mse_bwd(const float* a, const float* b, const float* dloss, long n, float* da, void* stream);
+size_t ocean_diversity_workspace(int B, int E);
+int ocean_diversity_fwd(const float* x, int B, int E, float* ws, size_t ws_floats, float* loss, void* stream);
+int ocean_diversity_bwd(int B, int E, float* ws /* from fwd */, const float* dloss, float* dx, void* stream);
+
 /* ------------------------------------------------------------------ clip + Adam
  * Replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step as used at
  * ocean/models/training/online_learner.py:325-335, 402-412 (Adam constructed

@@ -307,7 +307,8 @@ int launch_mode(GemmP p, bool aligned, hipStream_t stream) {
   // tile choice: wide tiles only when they still fill the chip
   const bool big_m = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128) >= 256;
   int bm, bn;
-  if (p.N > 64 && big_m) { bm = 128; bn = 128; }
+  if (AKM && p.M >= 128 && p.N >= 128) { bm = 128; bn = 128; }      // row reductions fill the chip through split-K
+  else if (p.N > 64 && big_m) { bm = 128; bn = 128; }
   else if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 256) { bm = 128; bn = 64; }
   else { bm = 64; bn = 64; }
   if (AKM && p.split_k <= 0) {

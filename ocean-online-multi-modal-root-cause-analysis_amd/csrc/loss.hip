@@ -121,6 +121,44 @@ __global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restr
     dp[i] = g * (p[i] - y[i]) / fmaxf(p[i] * (1.0f - p[i]), 1e-12f);
 }
 
+// loss += mean((a-b)^2)
+__global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float inv_n,
+                                                      float* __restrict__ loss) {
+  __shared__ float red[kWaves];
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { const float d = a[i] - b[i]; s += d * d; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+__global__ void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ dloss, long n,
+                               float inv_n, float* __restrict__ da) {
+  const float g = 2.0f * (dloss ? dloss[0] : 1.0f) * inv_n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) da[i] = g * (a[i] - b[i]);
+}
+// loss += sum_{i != j} |S[i,j]| * inv_pairs   over a [B,B] similarity matrix
+__global__ __launch_bounds__(256) void offdiag_abs_fwd_kernel(const float* __restrict__ S, int B, float inv_pairs, float* __restrict__ loss) {
+  __shared__ float red[kWaves];
+  const long n = (long)B * B;
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    if (i / B != i % B) s += fabsf(S[i]);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_pairs);
+}
+// S[i,j] <- sign(S[i,j]) * dloss * inv_pairs * 2 off the diagonal, 0 on it (S is symmetric: dF = (dS + dS^T) F = 2 dS F)
+__global__ void offdiag_abs_bwd_kernel(float* __restrict__ S, int B, float inv_pairs, const float* __restrict__ dloss) {
+  const long n = (long)B * B;
+  const float g = 2.0f * (dloss ? dloss[0] : 1.0f) * inv_pairs;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = S[i];
+    S[i] = (i / B != i % B) ? (v > 0.f ? g : (v < 0.f ? -g : 0.f)) : 0.f;
+  }
+}
+
 inline int egrid(long n) {
   long g = (n + 255) / 256;
   if (g > 4096) g = 4096;
@@ -277,6 +315,49 @@ int ocean_head_bwd(const ocean_head_shape* s, const float* x, float* const* P_, 
   OCEAN_TRY(linear_bwd_weight(d1, s->h1, x, s->E, G_[0], B, s->h1, s->E, st));
   OCEAN_TRY(colsum_add(d1, s->h1, B, s->h1, G_[1], st));
   if (dx) OCEAN_TRY(linear_bwd_data(d1, s->h1, P_[0], dx, s->E, B, s->h1, s->E, 0, st));
+  return OCEAN_OK;
+}
+
+// ---------------------------------------------------------------- Trainer's extra loss terms
+int ocean_mse_fwd(const float* a, const float* b, long n, float* loss, void* stream) {
+  if (!a || !b || !loss) return OCEAN_ERR_NULL;
+  if (n <= 0) return OCEAN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(mse_fwd_kernel, dim3(egrid(n) > 512 ? 512 : egrid(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, 1.0f / (float)n, loss);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+int ocean_mse_bwd(const float* a, const float* b, const float* dloss, long n, float* da, void* stream) {
+  if (!a || !b || !da) return OCEAN_ERR_NULL;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, a, b, dloss, n, 1.0f / (float)n, da);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+size_t ocean_diversity_workspace(int B, int E) { return al4((size_t)B * E) + al4(B) + al4((size_t)B * B); }
+int ocean_diversity_fwd(const float* x, int B, int E, float* ws, size_t ws_floats, float* loss, void* stream) {
+  if (!x || !ws || !loss) return OCEAN_ERR_NULL;
+  if (B <= 0 || E <= 0) return OCEAN_ERR_BAD_SHAPE;
+  if (ws_floats < ocean_diversity_workspace(B, E)) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* fh = ws; float* nrm = ws + al4((size_t)B * E); float* S = nrm + al4(B);
+  OCEAN_TRY(l2norm_fwd(x, E, fh, E, nrm, B, E, 1e-12f, st));
+  GemmP g = gemm_defaults();
+  g.A = fh; g.lda = E; g.B = fh; g.ldb = E; g.C = S; g.ldc = B; g.M = B; g.N = B; g.K = E;
+  OCEAN_TRY(ocean_launch_gemm(g, st));
+  // torch: mean over an empty selection is NaN when B == 1
+  const float inv_pairs = 1.0f / ((float)B * (float)(B - 1));
+  hipLaunchKernelGGL(offdiag_abs_fwd_kernel, dim3(egrid((long)B * B) > 512 ? 512 : egrid((long)B * B)), dim3(256), 0, st, S, B,
+                     B > 1 ? inv_pairs : NAN, loss);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+int ocean_diversity_bwd(int B, int E, float* ws, const float* dloss, float* dx, void* stream) {
+  if (!ws || !dx) return OCEAN_ERR_NULL;
+  hipStream_t st = (hipStream_t)stream;
+  float* fh = ws; float* nrm = ws + al4((size_t)B * E); float* S = nrm + al4(B);
+  hipLaunchKernelGGL(offdiag_abs_bwd_kernel, dim3(egrid((long)B * B)), dim3(256), 0, st, S, B, 1.0f / ((float)B * (float)(B - 1)), dloss);
+  OCEAN_LAUNCH_CHECK();
+  OCEAN_TRY(linear_bwd_data(S, B, fh, dx, E, B, B, E, 0, st));        // dF = dS . F   ([B,B] . [B,E])
+  OCEAN_TRY(l2norm_bwd(dx, E, fh, E, nrm, dx, E, B, E, 1e-12f, st));
   return OCEAN_OK;
 }
 

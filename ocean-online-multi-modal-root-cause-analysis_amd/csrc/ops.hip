@@ -32,16 +32,28 @@ namespace {
 
 // Each block reduces ROWS rows of up to 256 columns; threads run along columns
 // (coalesced row reads), one atomic per column per block.
-constexpr int kColsumRows = 128;
+// Block = 64 column lanes x 4 row lanes over kColsumRows rows: each wave reads 256 contiguous bytes per row,
+// four independent accumulators per thread keep loads in flight; one atomic per column per block.
+constexpr int kColsumRows = 1024;
 
-__global__ void colsum_kernel(const float* __restrict__ a, int lda, int M, int N, float* __restrict__ out) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int lda, int M, int N, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
   const int r0 = blockIdx.y * kColsumRows;
   const int r1 = min(M, r0 + kColsumRows);
-  float s = 0.f;
-  for (int r = r0; r < r1; ++r) s += a[(long)r * lda + col];
-  unsafeAtomicAdd(out + col, s);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < N) {
+    int r = r0 + ty;
+    for (; r + 12 < r1; r += 16) {
+      s0 += a[(long)r * lda + col]; s1 += a[(long)(r + 4) * lda + col];
+      s2 += a[(long)(r + 8) * lda + col]; s3 += a[(long)(r + 12) * lda + col];
+    }
+    for (; r < r1; r += 4) s0 += a[(long)r * lda + col];
+  }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && col < N) unsafeAtomicAdd(out + col, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
 }
 
 __global__ void relu_bwd_kernel(float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int M, int N) {
@@ -77,9 +89,8 @@ inline int grid_for(long n, int block = 256, int cap = 4096) {
 
 int colsum_add(const float* a, int lda, int M, int N, float* out, hipStream_t s) {
   if (M <= 0 || N <= 0) return OCEAN_ERR_BAD_SHAPE;
-  const int bx = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
-  dim3 grid(ceil_div(N, bx), ceil_div(M, kColsumRows));
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(bx), 0, s, a, lda, M, N, out);
+  dim3 grid(ceil_div(N, 64), ceil_div(M, kColsumRows));
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, a, lda, M, N, out);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }

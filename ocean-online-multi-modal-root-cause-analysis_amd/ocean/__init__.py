@@ -3,6 +3,6 @@ on AMD MI355X: the reference's Python API over hand-written gfx950 kernels."""
 __version__ = "0.1.0"
 
 from .configs.default_config import OCEANConfig, default_config, get_device
-from .models import OCEANModel, OnlineLearner
+from .models import OCEANModel, OnlineLearner, Trainer
 
-__all__ = ["OCEANConfig", "default_config", "get_device", "OCEANModel", "OnlineLearner"]
+__all__ = ["OCEANConfig", "default_config", "get_device", "OCEANModel", "Trainer", "OnlineLearner"]

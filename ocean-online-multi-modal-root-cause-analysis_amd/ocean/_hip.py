@@ -116,6 +116,11 @@ def _declare_rest(lib) -> None:
     sig("ocean_bce_fwd", c_int, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_bce_bwd", c_int, vp, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_mean_mid_f32", c_int, vp, vp, c_int, c_int, c_int, vp)
+    sig("ocean_mse_fwd", c_int, vp, vp, c_long, vp, vp)
+    sig("ocean_mse_bwd", c_int, vp, vp, vp, c_long, vp, vp)
+    sig("ocean_diversity_workspace", c_size_t, c_int, c_int)
+    sig("ocean_diversity_fwd", c_int, vp, c_int, c_int, vp, c_size_t, vp, vp)
+    sig("ocean_diversity_bwd", c_int, c_int, c_int, vp, vp, vp, vp)
     sig("ocean_prof_enable", c_int, c_int)
     sig("ocean_prof_summary", c_int, ctypes.c_char_p, c_size_t)
     sig("ocean_grad_sqnorm", c_int, vp, c_int, vp, vp)
@@ -180,6 +185,21 @@ def ptr_table(tensors: Sequence[Optional[torch.Tensor]], name: str):
 def new_seed(p: float) -> int:
     """A fresh dropout seed from torch's CPU generator (0 when dropout is inactive)."""
     return int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+
+
+def zero_grads_like(params, skip=None):
+    """Zero-initialised gradient buffers for `params` as views of ONE flat allocation (one fill kernel
+    instead of one per tensor).  skip[i] True -> None for that slot."""
+    sizes = [0 if (skip is not None and skip[i]) else (p.numel() + 3) // 4 * 4 for i, p in enumerate(params)]
+    total = sum(sizes)
+    if total == 0:
+        return [None] * len(params)
+    flat = torch.zeros(total, device=params[0].device, dtype=torch.float32)
+    out, off = [], 0
+    for p, n in zip(params, sizes):
+        out.append(None if n == 0 else flat[off: off + p.numel()].view_as(p))
+        off += n
+    return out
 
 
 def stream() -> c_void_p:

@@ -1,5 +1,6 @@
 from .components import DilatedCNN, GraphFusionModule, GraphNeuralNetwork, MultiFactorAttention
 from .ocean_model import OCEANModel
-from .training import OnlineLearner
+from .training import LossFunction, OnlineLearner, StreamingHandler, Trainer
 
-__all__ = ["OCEANModel", "DilatedCNN", "GraphNeuralNetwork", "MultiFactorAttention", "GraphFusionModule", "OnlineLearner"]
+__all__ = ["OCEANModel", "DilatedCNN", "GraphNeuralNetwork", "MultiFactorAttention", "GraphFusionModule",
+           "Trainer", "OnlineLearner", "StreamingHandler", "LossFunction"]

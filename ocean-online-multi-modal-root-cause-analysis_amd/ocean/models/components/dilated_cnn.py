@@ -82,7 +82,7 @@ class _DcnnFunction(torch.autograd.Function):
         dout = dout.contiguous()
         wb = torch.empty(L.ocean_dcnn_bwd_workspace(ctypes.byref(shape)), device=x.device, dtype=torch.float32)
         is_stat = module._stat_slots()
-        grads = [None if is_stat[i] else torch.zeros_like(p) for i, p in enumerate(params)]
+        grads = _hip.zero_grads_like(params, skip=is_stat)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ptab = _hip.ptr_table(params, "dcnn param")
         gtab = _hip.ptr_table(grads, "dcnn grad")

@@ -153,7 +153,7 @@ class _FusionFunction(torch.autograd.Function):
         t, s, l, ws, X, Zp, *params = ctx.saved_tensors
         sh = ctx.sh
         wb = torch.empty(L.ocean_fusion_bwd_workspace(ctypes.byref(sh)), device=t.device, dtype=torch.float32)
-        grads = [torch.zeros_like(p) for p in params]
+        grads = _hip.zero_grads_like(params)
         dt = torch.empty_like(t) if ctx.needs_input_grad[0] else None
         ds = torch.empty_like(s) if ctx.needs_input_grad[1] else None
         dl = torch.empty_like(l) if ctx.needs_input_grad[2] else None

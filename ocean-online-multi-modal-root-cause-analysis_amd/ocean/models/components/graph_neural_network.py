@@ -106,7 +106,7 @@ class _GnnFunction(torch.autograd.Function):
         nf, ws, *params = ctx.saved_tensors
         s, graph = ctx.s, ctx.graph
         wb = torch.empty(L.ocean_gnn_bwd_workspace(ctypes.byref(s)), device=nf.device, dtype=torch.float32)
-        grads = [torch.zeros_like(p) for p in params]
+        grads = _hip.zero_grads_like(params)
         _hip.check(L.ocean_gnn_bwd(ctypes.byref(s), _hip.dev_ptr(nf), graph.table, _hip.ptr_table(params, "gnn param"),
                                    _hip.dev_ptr(ws), _hip.dev_ptr(wb), wb.numel(), _hip.dev_ptr(dout.contiguous(), "grad_output"),
                                    _hip.ptr_table(grads, "gnn grad"), _hip.stream()), "ocean_gnn_bwd")

@@ -91,7 +91,7 @@ class _MfaFunction(torch.autograd.Function):
         t, s, l, ws, *params = ctx.saved_tensors
         sh = ctx.sh
         wb = torch.empty(L.ocean_mfa_bwd_workspace(ctypes.byref(sh)), device=t.device, dtype=torch.float32)
-        grads = [torch.zeros_like(p) for p in params]
+        grads = _hip.zero_grads_like(params)
         dt = torch.empty_like(t) if ctx.needs_input_grad[0] else None
         ds = torch.empty_like(s) if ctx.needs_input_grad[1] else None
         dl = torch.empty_like(l) if ctx.needs_input_grad[2] else None

@@ -52,7 +52,7 @@ class _HeadFunction(torch.autograd.Function):
         x, ws, probs, *params = ctx.saved_tensors
         sh = ctx.sh
         wb = torch.empty(L.ocean_head_bwd_workspace(ctypes.byref(sh)), device=x.device, dtype=torch.float32)
-        grads = [torch.zeros_like(p) for p in params]
+        grads = _hip.zero_grads_like(params)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         c = lambda g: None if g is None else g.contiguous()
         _hip.check(L.ocean_head_bwd(ctypes.byref(sh), _hip.dev_ptr(x), _hip.ptr_table(params, "head param"), _hip.dev_ptr(ws),

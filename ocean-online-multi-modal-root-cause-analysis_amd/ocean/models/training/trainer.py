@@ -1,0 +1,266 @@
+"""Batch trainer: LossFunction and the epoch step on MI355X.
+
+LossFunction reproduces the arithmetic of the reference's
+(ocean/models/training/trainer.py:29-120): BCE + 0.1 * sum of InfoNCE terms
++ 0.05 * MSE(temporal_t, temporal_{t-1}) + 0.02 * mean |off-diagonal cosine of
+the fused batch|, every term a HIP kernel.  Trainer keeps the reference's
+constructor and train() / _train_epoch / _validate_epoch / checkpoint methods
+(trainer.py:245-645) for any loader that yields the reference's batch
+dictionaries ('metrics', 'logs', 'labels', 'graphs').
+
+The reference's own loop cannot finish an epoch (it calls .item() on Python
+floats, trainer.py:91,430, and reads a 'val_loss' key it never writes,
+:358); here scalar terms are handled and validation is monitored on
+'val_total_loss'.  Plotting and wandb logging are host tooling outside the
+model path and are not provided.
+"""
+from __future__ import annotations
+
+import json
+import logging
+from collections import defaultdict
+from datetime import datetime
+from pathlib import Path
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from ... import ops
+from ...configs import OCEANConfig
+from ...optim import FusedAdam
+from ..ocean_model import OCEANModel
+
+logger = logging.getLogger(__name__)
+
+
+class LossFunction(nn.Module):
+    def __init__(self, prediction_weight: float = 1.0, contrastive_weight: float = 0.1, consistency_weight: float = 0.05,
+                 diversity_weight: float = 0.02):
+        super().__init__()
+        self.prediction_weight, self.contrastive_weight = prediction_weight, contrastive_weight
+        self.consistency_weight, self.diversity_weight = consistency_weight, diversity_weight
+
+    def forward(self, predictions: Dict[str, Any], targets: torch.Tensor, temporal_features: Optional[torch.Tensor] = None,
+                prev_temporal_features: Optional[torch.Tensor] = None) -> Dict[str, Any]:
+        losses: Dict[str, Any] = {}
+        probs = predictions["root_cause_probs"]
+        pred_loss = ops.binary_cross_entropy(probs, targets.to(probs.device))
+        losses["prediction_loss"] = pred_loss
+        total_c: Any = 0.0
+        for name, value in predictions.get("contrastive_losses", {}).items():
+            losses[f"contrastive_{name}"] = value
+            total_c = total_c + value
+        losses["total_contrastive_loss"] = total_c
+        consistency: Any = 0.0
+        if temporal_features is not None and prev_temporal_features is not None:
+            consistency = ops.mse_loss(temporal_features, prev_temporal_features)
+        losses["consistency_loss"] = consistency
+        diversity: Any = 0.0
+        inter = predictions.get("intermediate")
+        if inter is not None and "fused_representation" in inter:
+            diversity = ops.diversity_loss(inter["fused_representation"])
+        losses["diversity_loss"] = diversity
+        losses["total_loss"] = (self.prediction_weight * pred_loss + self.contrastive_weight * total_c +
+                                self.consistency_weight * consistency + self.diversity_weight * diversity)
+        return losses
+
+
+class EarlyStopping:
+    def __init__(self, patience: int = 10, min_delta: float = 1e-4, monitor: str = "val_loss", mode: str = "min",
+                 restore_best_weights: bool = True):
+        self.patience, self.monitor, self.mode, self.restore_best_weights = patience, monitor, mode, restore_best_weights
+        self.min_delta = -min_delta if mode == "min" else min_delta
+        self.monitor_op = np.less if mode == "min" else np.greater
+        self.wait = self.stopped_epoch = 0
+        self.best_value: Optional[float] = None
+        self.best_weights = None
+
+    def _snapshot(self, model: nn.Module):
+        return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    def __call__(self, current_value: float, model: nn.Module) -> bool:
+        if self.best_value is None or self.monitor_op(current_value - self.min_delta, self.best_value):
+            first = self.best_value is None
+            self.best_value, self.best_weights = current_value, self._snapshot(model)
+            if not first:
+                self.wait = 0
+            return False
+        self.wait += 1
+        if self.wait >= self.patience:
+            self.stopped_epoch = self.wait
+            if self.restore_best_weights and self.best_weights:
+                model.load_state_dict(self.best_weights)
+            return True
+        return False
+
+
+class LearningRateScheduler:
+    def __init__(self, optimizer: optim.Optimizer, scheduler_type: str = "cosine", **kw):
+        self.optimizer, self.scheduler_type = optimizer, scheduler_type
+        sched = optim.lr_scheduler
+        if scheduler_type == "cosine":
+            self.scheduler = sched.CosineAnnealingLR(optimizer, T_max=kw.get("T_max", 100), eta_min=kw.get("eta_min", 1e-6))
+        elif scheduler_type == "step":
+            self.scheduler = sched.StepLR(optimizer, step_size=kw.get("step_size", 30), gamma=kw.get("gamma", 0.1))
+        elif scheduler_type == "plateau":
+            self.scheduler = sched.ReduceLROnPlateau(optimizer, mode=kw.get("mode", "min"), factor=kw.get("factor", 0.5),
+                                                     patience=kw.get("patience", 10), min_lr=kw.get("min_lr", 1e-6))
+        elif scheduler_type == "exponential":
+            self.scheduler = sched.ExponentialLR(optimizer, gamma=kw.get("gamma", 0.95))
+        else:
+            raise ValueError(f"Unknown scheduler type: {scheduler_type}")
+
+    def step(self, metric: Optional[float] = None):
+        if self.scheduler_type == "plateau":
+            if metric is not None:
+                self.scheduler.step(metric)
+        else:
+            self.scheduler.step()
+
+    def get_last_lr(self) -> List[float]:
+        return self.scheduler.get_last_lr()
+
+
+class Trainer:
+    def __init__(self, model: OCEANModel, config: OCEANConfig, data_loader: Any, optimizer: Optional[optim.Optimizer] = None,
+                 device: Optional[torch.device] = None, use_wandb: bool = False):
+        if use_wandb:
+            raise NotImplementedError("wandb logging is not part of the MI355X model path")
+        self.model, self.config, self.data_loader = model, config, data_loader
+        self.device = device if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.model.to(self.device)
+        self.optimizer = optimizer if optimizer is not None else FusedAdam(
+            model.parameters(), lr=config.training.learning_rate, weight_decay=config.training.weight_decay)
+        self.loss_function = LossFunction(prediction_weight=config.training.prediction_loss_weight,
+                                          contrastive_weight=config.training.contrastive_loss_weight)
+        self.early_stopping = EarlyStopping(patience=config.training.early_stopping_patience,
+                                            min_delta=config.training.early_stopping_delta)
+        self.lr_scheduler = LearningRateScheduler(self.optimizer, scheduler_type=config.training.scheduler)
+        self.current_epoch = 0
+        self.train_history, self.val_history = defaultdict(list), defaultdict(list)
+        self.best_val_loss = float("inf")
+        self.training_start_time: Optional[datetime] = None
+        self.online_learner = None
+        self.prev_temporal_features: Optional[torch.Tensor] = None
+        self.grad_sync = None                      # data-parallel hook, see ocean.parallel
+
+    # ------------------------------------------------------------------ one batch
+    def _move_batch_to_device(self, batch: Dict[str, Any]) -> Dict[str, Any]:
+        return {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def _batch_losses(self, batch: Dict[str, Any]) -> Dict[str, Any]:
+        out = self.model(batch["metrics"], batch["graphs"][0], batch["logs"], return_intermediate=True)
+        temporal = out["intermediate"]["temporal_features"]
+        prev = self.prev_temporal_features
+        if prev is not None and prev.shape != temporal.shape:     # a ragged last batch has no predecessor of its shape
+            prev = None
+        losses = self.loss_function(out, batch["labels"], temporal, prev)
+        return out, losses
+
+    @staticmethod
+    def _to_host(losses: Dict[str, Any]) -> Dict[str, float]:
+        keys = [k for k, v in losses.items() if torch.is_tensor(v)]
+        vals = torch.stack([losses[k].detach().float().reshape(()) for k in keys]).cpu().tolist() if keys else []
+        host = dict(zip(keys, vals))
+        host.update({k: float(v) for k, v in losses.items() if not torch.is_tensor(v)})
+        return host
+
+    def train_step(self, batch: Dict[str, Any]) -> Dict[str, float]:
+        """Forward, LossFunction, backward, clip, optimizer step on one batch dictionary (trainer.py:395-434)."""
+        self.model.train()
+        batch = self._move_batch_to_device(batch)
+        out, losses = self._batch_losses(batch)
+        self.optimizer.zero_grad()
+        losses["total_loss"].backward()
+        if self.grad_sync is not None:
+            self.grad_sync(self.model)
+        clip = self.config.training.gradient_clip_norm
+        if isinstance(self.optimizer, FusedAdam):
+            self.optimizer.step(max_norm=clip if clip > 0 else 0.0)
+        else:
+            if clip > 0:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)
+            self.optimizer.step()
+        self.prev_temporal_features = out["intermediate"]["temporal_features"].detach()
+        return self._to_host(losses)
+
+    def _train_epoch(self, train_loader) -> Dict[str, float]:
+        sums = defaultdict(list)
+        for batch in train_loader:
+            for k, v in self.train_step(batch).items():
+                sums[k].append(v)
+        return {f"train_{k}": float(np.mean(v)) for k, v in sums.items()}
+
+    def _validate_epoch(self, val_loader) -> Dict[str, float]:
+        self.model.eval()
+        sums = defaultdict(list)
+        with torch.no_grad():
+            for batch in val_loader:
+                _, losses = self._batch_losses(self._move_batch_to_device(batch))
+                for k, v in self._to_host(losses).items():
+                    sums[k].append(v)
+        return {f"val_{k}": float(np.mean(v)) for k, v in sums.items()}
+
+    # ------------------------------------------------------------------ epochs
+    def train(self, num_epochs: Optional[int] = None) -> Dict[str, Any]:
+        num_epochs = self.config.training.num_epochs if num_epochs is None else num_epochs
+        self.training_start_time = datetime.now()
+        train_loader, val_loader, _ = self.data_loader.get_all_loaders()
+        try:
+            for epoch in range(num_epochs):
+                self.current_epoch = epoch
+                tm = self._train_epoch(train_loader)
+                vm = self._validate_epoch(val_loader)
+                val_loss = vm.get("val_total_loss", float("nan"))
+                self.lr_scheduler.step(val_loss)
+                for k, v in tm.items():
+                    self.train_history[k].append(v)
+                for k, v in vm.items():
+                    self.val_history[k].append(v)
+                self.best_val_loss = min(self.best_val_loss, val_loss)
+                if self.early_stopping(val_loss, self.model):
+                    logger.info("Early stopping at epoch %d", epoch)
+                    break
+                if (epoch + 1) % self.config.training.save_checkpoint_every == 0:
+                    self._save_checkpoint(epoch, val_loss)
+        except KeyboardInterrupt:
+            logger.info("Training interrupted by user")
+        finally:
+            self._save_final_model()
+        return {"train_history": dict(self.train_history), "val_history": dict(self.val_history)}
+
+    # ------------------------------------------------------------------ checkpoints
+    def _checkpoint_dict(self, epoch: int, val_loss: float) -> Dict[str, Any]:
+        return {"epoch": epoch, "model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
+                "scheduler_state_dict": self.lr_scheduler.scheduler.state_dict(), "val_loss": val_loss,
+                "train_history": dict(self.train_history), "val_history": dict(self.val_history),
+                "config": self.config.to_dict()}
+
+    def _save_checkpoint(self, epoch: int, val_loss: float):
+        d = Path(self.config.training.checkpoint_dir)
+        d.mkdir(parents=True, exist_ok=True)
+        torch.save(self._checkpoint_dict(epoch, val_loss), d / f"checkpoint_epoch_{epoch + 1}.pt")
+
+    def _save_final_model(self):
+        d = Path(self.config.training.checkpoint_dir)
+        d.mkdir(parents=True, exist_ok=True)
+        torch.save({"model_state_dict": self.model.state_dict(), "config": self.config.to_dict(),
+                    "training_completed": datetime.now().isoformat(), "total_epochs": self.current_epoch + 1,
+                    "best_val_loss": self.best_val_loss}, d / "final_model.pt")
+        with open(d / "training_history.json", "w") as f:
+            json.dump({"train_history": dict(self.train_history), "val_history": dict(self.val_history)}, f, indent=2)
+
+    def load_checkpoint(self, checkpoint_path: str):
+        ckpt = torch.load(checkpoint_path, map_location=self.device, weights_only=False)
+        self.model.load_state_dict(ckpt["model_state_dict"])
+        self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+        if "scheduler_state_dict" in ckpt:
+            self.lr_scheduler.scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+        self.current_epoch = ckpt.get("epoch", 0)
+        for k, v in ckpt.get("train_history", {}).items():
+            self.train_history[k] = v
+        for k, v in ckpt.get("val_history", {}).items():
+            self.val_history[k] = v

@@ -102,3 +102,58 @@ def mean_tokens(x: torch.Tensor) -> torch.Tensor:
     _hip.check(_hip.lib().ocean_mean_mid_f32(_hip.dev_ptr(x, "logs"), _hip.dev_ptr(out), x.shape[0], x.shape[1], x.shape[2],
                                              _hip.stream()), "ocean_mean_mid_f32")
     return out
+
+
+class _Mse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        loss = torch.zeros((), device=a.device, dtype=torch.float32)
+        _hip.check(_hip.lib().ocean_mse_fwd(_hip.dev_ptr(a), _hip.dev_ptr(b), a.numel(), _hip.dev_ptr(loss), _hip.stream()), "ocean_mse_fwd")
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        a, b = ctx.saved_tensors
+        da = torch.empty_like(a)
+        _hip.check(_hip.lib().ocean_mse_bwd(_hip.dev_ptr(a), _hip.dev_ptr(b), _hip.dev_ptr(dloss.contiguous().float()), a.numel(),
+                                            _hip.dev_ptr(da), _hip.stream()), "ocean_mse_bwd")
+        return da, None
+
+
+def mse_loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """nn.MSELoss()(a, b) with the gradient flowing to `a` (trainer.py:94: b is the detached previous batch)."""
+    if a.shape != b.shape:
+        raise ValueError(f"mse_loss needs equal shapes, got {tuple(a.shape)} and {tuple(b.shape)}")
+    return _Mse.apply(a.contiguous().float(), b.detach().contiguous().float())
+
+
+class _Diversity(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L = _hip.lib()
+        B, E = x.shape
+        ws = torch.empty(L.ocean_diversity_workspace(B, E), device=x.device, dtype=torch.float32)
+        loss = torch.zeros((), device=x.device, dtype=torch.float32)
+        _hip.check(L.ocean_diversity_fwd(_hip.dev_ptr(x), B, E, _hip.dev_ptr(ws), ws.numel(), _hip.dev_ptr(loss), _hip.stream()),
+                   "ocean_diversity_fwd")
+        ctx.shape = (B, E)
+        ctx.save_for_backward(ws)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (ws,) = ctx.saved_tensors
+        B, E = ctx.shape
+        dx = torch.empty(B, E, device=ws.device, dtype=torch.float32)
+        ws = ws.clone()                      # backward overwrites the similarity matrix; keep double-backward-free reuse safe
+        _hip.check(_hip.lib().ocean_diversity_bwd(B, E, _hip.dev_ptr(ws), _hip.dev_ptr(dloss.contiguous().float()), _hip.dev_ptr(dx),
+                                                  _hip.stream()), "ocean_diversity_bwd")
+        return dx
+
+
+def diversity_loss(x: torch.Tensor) -> torch.Tensor:
+    """mean over i != j of |cos(x_i, x_j)| (trainer.py:97-108)."""
+    if x.dim() != 2:
+        raise ValueError("expected [batch, dim]")
+    return _Diversity.apply(x.contiguous().float())

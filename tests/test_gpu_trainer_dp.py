@@ -1,0 +1,169 @@
+"""GPU tests of the Trainer's LossFunction / train_step, the streaming front-end
+with the real learner, and 2-rank data parallelism on the HIP path (two
+processes sharing the one GPU, gloo transport) against the single-process
+full-batch oracle."""
+import os
+import socket
+from datetime import datetime
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ocean_ref as R
+from oracle import synth
+from test_gpu_model import T, build, close, graph_of, tiny_config, zero_dropout
+
+pytestmark = pytest.mark.gpu
+
+
+def test_trainer_loss_function_matches_reference_fixture(golden):
+    from ocean.models.training import LossFunction
+    g = golden("model_train_tiny_bank")
+    sd = {k[3:]: T(g[k]).clone() for k in g.files if k.startswith("sd/")}
+    m = build(tiny_config(), sd).train()
+    out = m(T(g["s0/metrics"]), graph_of(g), T(g["s0/logs"]), return_intermediate=True)
+    temporal = out["intermediate"]["temporal_features"]
+    losses = LossFunction()(out, T(g["s0/labels"]).cuda(), temporal, temporal.detach() * 0.9)
+    for k in g.files:
+        if k.startswith("trainer_loss/"):
+            close(torch.as_tensor(losses[k[13:]]), g[k], 1e-3)
+    # gradients of the two extra terms against torch autograd on the same device values
+    f = out["intermediate"]["fused_representation"].detach().cpu().requires_grad_(True)
+    tm = temporal.detach().cpu().requires_grad_(True)
+    ref = R.trainer_loss({"root_cause_probs": out["root_cause_probs"].detach().cpu(), "temporal_features": tm,
+                          "fused_representation": f}, T(g["s0/labels"]), tm.detach() * 0.9)
+    (0.05 * ref["consistency_loss"] + 0.02 * ref["diversity_loss"]).backward()
+    from ocean import ops
+    fd = out["intermediate"]["fused_representation"].detach().requires_grad_(True)
+    td = temporal.detach().requires_grad_(True)
+    (0.05 * ops.mse_loss(td, td.detach() * 0.9) + 0.02 * ops.diversity_loss(fd)).backward()
+    close(fd.grad, f.grad, 1e-3)
+    close(td.grad, tm.grad, 1e-3)
+
+
+def test_trainer_train_step_and_epoch_loop(tmp_path):
+    import ocean
+    from ocean.data import ServiceGraph
+    from ocean.models.training import Trainer
+    cfg = tiny_config()
+    cfg.training.checkpoint_dir = str(tmp_path)
+    cfg.training.save_checkpoint_every = 1
+    m = ocean.OCEANModel(cfg)
+    zero_dropout(m)
+    sg = ServiceGraph(synth.random_digraph(6, 2.0, 1), torch.randn(6, 7))
+
+    def batch(seed, B=4):
+        g = torch.Generator().manual_seed(seed)
+        lab = torch.zeros(B, 6)
+        lab[torch.arange(B), torch.randint(0, 6, (B,), generator=g)] = 1
+        return {"metrics": torch.randn(B, 8, 5, generator=g), "logs": torch.randn(B, 24, generator=g), "labels": lab,
+                "graphs": [sg] * B, "timestamps": [datetime(2024, 1, 1)] * B}
+
+    class Loaders:
+        def get_all_loaders(self):
+            return [batch(1), batch(2), batch(3, B=3)], [batch(4)], [batch(5)]
+
+    tr = Trainer(m, cfg, Loaders())
+    first = tr.train_step(batch(0))
+    assert set(first) >= {"prediction_loss", "total_contrastive_loss", "consistency_loss", "diversity_loss", "total_loss"}
+    assert first["consistency_loss"] == 0.0 and np.isfinite(first["total_loss"])
+    second = tr.train_step(batch(0))
+    assert second["consistency_loss"] > 0.0
+    hist = tr.train(num_epochs=2)
+    assert len(hist["train_history"]["train_total_loss"]) == 2 and len(hist["val_history"]["val_total_loss"]) == 2
+    assert (tmp_path / "final_model.pt").exists() and (tmp_path / "checkpoint_epoch_2.pt").exists()
+    tr.load_checkpoint(str(tmp_path / "checkpoint_epoch_2.pt"))
+
+
+def test_streaming_handler_drives_real_updates():
+    import ocean
+    from ocean.data import DatasetSample, ServiceGraph
+    from ocean.models.training import OnlineLearner, StreamingHandler
+    cfg = tiny_config()
+    m = ocean.OCEANModel(cfg).cuda()
+    learner = OnlineLearner(m, cfg)
+    h = StreamingHandler(learner, max_concurrent_streams=4, processing_interval=0.05)
+    sg = ServiceGraph(synth.random_digraph(6, 2.0, 1), torch.randn(6, 7))
+    for s in range(4):
+        assert h.create_stream(f"s{s}")
+        for i in range(3):                 # 3 per stream -> one batch of 12 (<= 5 per modality keeps the bank in its safe range or not: ring handles it)
+            lab = torch.zeros(6)
+            lab[(s + i) % 6] = 1
+            h.add_sample_to_stream(f"s{s}", DatasetSample(torch.randn(8, 5), torch.randn(24), sg, lab, datetime.now()))
+    w0 = m.prediction_head[0].weight.detach().clone()
+    assert h.stream_processor.process_once() == 12
+    assert learner.update_count == 1 and not torch.equal(w0, m.prediction_head[0].weight)
+    assert h.get_comprehensive_stats()["learner_stats"]["total_updates"] == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, fix, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ocean
+        from ocean.data import ServiceGraph
+        from ocean.models.training import OnlineLearner
+        from ocean.parallel import DataParallel
+        cfg = tiny_config()
+        m = ocean.OCEANModel(cfg)
+        zero_dropout(m)
+        m.load_state_dict({k: v.clone() for k, v in fix["sd"].items()})
+        m = m.cuda()
+        m.contrastive_negatives = "in_batch"
+        learner = OnlineLearner(m, cfg)
+        DataParallel(m, learner)
+        B = fix["metrics"].shape[0] // world
+        sl = slice(rank * B, (rank + 1) * B)
+        sg = ServiceGraph(fix["adj"], fix["nf"])
+        m.train()
+        o = m(fix["metrics"][sl], sg, fix["logs"][sl])
+        losses = m.compute_loss(o, fix["labels"][sl].cuda())
+        learner.optimizer.zero_grad()
+        losses["total_loss"].backward()
+        learner.grad_sync(m)
+        out[rank] = {"probs": o["root_cause_probs"].detach().cpu(), "loss": float(losses["total_loss"].detach()),
+                     "grads": {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None},
+                     "rm": m.temporal_encoder.conv_layers[1].batch_norm.running_mean.detach().cpu()}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_reproduce_single_process_full_batch():
+    import torch.multiprocessing as mp
+    import ocean
+    cfg = tiny_config()
+    m0 = ocean.OCEANModel(cfg)
+    sd = synth.fill_state_dict(m0.state_dict(), 21)
+    g = torch.Generator().manual_seed(5)
+    B = 8
+    fix = {"sd": sd, "metrics": torch.randn(B, 12, 5, generator=g), "logs": torch.randn(B, 24, generator=g),
+           "adj": synth.random_digraph(6, 2.0, 2), "nf": torch.randn(6, 7, generator=g), "labels": torch.zeros(B, 6)}
+    fix["labels"][torch.arange(B), torch.randint(0, 6, (B,), generator=g)] = 1
+    # single-process full-batch oracle
+    rsd = R.require_grad(sd)
+    ro = R.model_forward(rsd, fix["metrics"], fix["adj"], fix["nf"], fix["logs"], training=True, negatives="in_batch",
+                         dilations=(1, 2), gnn_heads=2, log_dim=24)
+    rl = R.compute_loss(ro, fix["labels"])
+    rl["total_loss"].backward()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, _free_port(), fix, out), nprocs=2, join=True)
+    probs = torch.cat([out[0]["probs"], out[1]["probs"]])
+    rel = ((probs - ro["root_cause_probs"]).abs() / ro["root_cause_probs"]).max().item()
+    assert rel < 1e-4, rel                                     # synchronised BatchNorm statistics: global-batch forward
+    assert abs((out[0]["loss"] + out[1]["loss"]) / 2 - float(rl["total_loss"])) < 1e-3 * abs(float(rl["total_loss"]))
+    for k, gref in ((k, v.grad) for k, v in rsd.items() if v.grad is not None):
+        for r in (0, 1):
+            close(out[r]["grads"][k], gref, 1e-3)              # averaged gradients == full-batch gradients, on both ranks
+    close(out[0]["rm"], rsd["temporal_encoder.conv_layers.1.batch_norm.running_mean"], 1e-5)

