@@ -423,6 +423,10 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
                          wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, M, C, layer_dropout(s, j));
     }
     OCEAN_LAUNCH_CHECK();
+    // gamma / beta gradients come from THIS rank's sums (before any cross-rank all-reduce of the block), so that
+    // averaging parameter gradients over ranks yields the global-batch gradient like every other parameter
+    hipLaunchKernelGGL(bn_bwd_param_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st, bs, grads[pi_bn(pl, j, 1)], grads[pi_bn(pl, j, 2)], C);
+    OCEAN_LAUNCH_CHECK();
     return OCEAN_OK;
   };
 
@@ -451,8 +455,6 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
     else
       hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(egrid(tot)), dim3(256), 0, st, dy, bT, dsc, wf + pl.u[j], wf + pl.scale[j],
                          wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, n, dU, tot, C, s->training, layer_dropout(s, j));
-    OCEAN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_param_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st, bs, grads[pi_bn(pl, j, 1)], grads[pi_bn(pl, j, 2)], C);
     OCEAN_LAUNCH_CHECK();
     const float* in = layer_input(pl, j, wf);
     if (pl.is_block[j]) {

@@ -106,14 +106,15 @@ def _free_port():
 
 
 def _dp_worker(rank, world, port, fix, out):
+    import faulthandler
     import torch.distributed as dist
+    faulthandler.dump_traceback_later(90, exit=True)       # a stuck rank reports where, instead of hanging the run
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import ocean
         from ocean.data import ServiceGraph
         from ocean.models.training import OnlineLearner
-        from ocean.parallel import DataParallel
         cfg = tiny_config()
         m = ocean.OCEANModel(cfg)
         zero_dropout(m)
@@ -121,7 +122,38 @@ def _dp_worker(rank, world, port, fix, out):
         m = m.cuda()
         m.contrastive_negatives = "in_batch"
         learner = OnlineLearner(m, cfg)
-        DataParallel(m, learner)
+
+        # The production wiring (ocean.parallel.DataParallel) issues RCCL collectives on device tensors; one GPU
+        # cannot host two RCCL ranks, so this test installs the same three hooks with host-staged gloo collectives.
+        def all_reduce_dev(t):
+            c = t.detach().cpu()
+            dist.all_reduce(c)
+            t.copy_(c)
+
+        class GatherRows(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                parts = [torch.zeros(x.shape) for _ in range(world)]
+                dist.all_gather(parts, x.detach().cpu())
+                return torch.cat(parts).to(x.device)
+
+            @staticmethod
+            def backward(ctx, g):
+                c = g.detach().cpu()
+                dist.all_reduce(c)
+                n = c.shape[0] // world
+                return c[rank * n:(rank + 1) * n].to(g.device)
+
+        def sync_grads(model):
+            for p in model.parameters():
+                if p.grad is not None:
+                    all_reduce_dev(p.grad)
+                    p.grad.div_(world)
+
+        enc, cm = m.temporal_encoder, m.fusion_module.contrastive_module
+        enc.stats_all_reduce, enc.stats_world_size = all_reduce_dev, world
+        cm.gather_positives, cm.rank_row_offset = GatherRows.apply, (lambda rows: rank * rows)
+        learner.grad_sync = sync_grads
         B = fix["metrics"].shape[0] // world
         sl = slice(rank * B, (rank + 1) * B)
         sg = ServiceGraph(fix["adj"], fix["nf"])
