@@ -43,6 +43,16 @@ int ocean_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, i
                    int M, int N, int K, int a_kmajor, int b_kn,
                    const float* bias, const float* R, int ldr, int relu, void* stream);
 
+/* The same GEMM with the dilated-convolution row shifts exposed (taps accumulate; rows are (sample,time)
+ * pairs with time = row % T; tap t reads rows shifted by shift0 + t*shift_step, zero outside [0,T)).
+ * a_kmajor == 0: shift on A's rows, B advances tap_stride_b per tap.  a_kmajor == 1: shift on B's rows,
+ * each tap accumulates into C + t*tap_stride_c, reduction split split_k ways (0 = automatic).
+ * This is the implicit-GEMM form of nn.Conv1d in DilatedConvBlock (dilated_cnn.py:48-55) and its two
+ * gradients; exported for kernel-level tests and benchmarks. */
+int ocean_conv_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                        int a_kmajor, int b_kn, int taps, int T, int shift0, int shift_step, long tap_stride_b,
+                        long tap_stride_c, int split_k, void* stream);
+
 /* out[G,C] = mean over the middle axis of a[G,n,C].  Replaces torch.mean(logs, dim=1) for
  * [B,L,768] log embeddings (ocean/models/ocean_model.py:179-181). */
 int ocean_mean_mid_f32(const float* a, float* out, int G, int n, int C, void* stream);

@@ -16,6 +16,17 @@ int ocean_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, i
   return ocean_launch_gemm(p, (hipStream_t)stream);
 }
 
+int ocean_conv_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                        int a_kmajor, int b_kn, int taps, int T, int shift0, int shift_step, long tap_stride_b,
+                        long tap_stride_c, int split_k, void* stream) {
+  GemmP p = gemm_defaults();
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.a_kmajor = a_kmajor; p.b_kn = b_kn;
+  p.taps = taps; p.T = T; p.shift0 = shift0; p.shift_step = shift_step;
+  p.tap_stride_b = tap_stride_b; p.tap_stride_c = tap_stride_c; p.split_k = split_k;
+  return ocean_launch_gemm(p, (hipStream_t)stream);
+}
+
 int ocean_mean_mid_f32(const float* a, float* out, int G, int n, int C, void* stream) {
   if (!a || !out) return OCEAN_ERR_NULL;
   if (G <= 0 || n <= 0 || C <= 0) return OCEAN_ERR_BAD_SHAPE;

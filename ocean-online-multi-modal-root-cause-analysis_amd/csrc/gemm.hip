@@ -18,6 +18,7 @@
 // prefetch) and written to the other LDS buffer afterwards: one barrier per tile.
 #include "common.h"
 #include <cstdio>
+#include <cstdlib>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -218,18 +219,28 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmP p) {
     if (it + 1 < n_iter) load_tiles(it + 1);
     const float* Ac = As + buf * BK * LDA + a_frag;
     const float* Bc = Bs + buf * BK * LDB + b_frag;
+    // fragments of k-step s+1 are read from LDS before the MFMAs of step s issue, so the LDS latency
+    // hides behind 4 x 64 cycles of matrix work instead of stalling every step
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = Ac[khalf * LDA + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = Bc[khalf * LDB + j * 32];
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
-      float a[TM], b[TN];
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = Ac[(2 * s + khalf) * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) a[nxt][i] = Ac[(2 * (s + 1) + khalf) * LDA + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bc[(2 * s + khalf) * LDB + j * 32];
+        for (int j = 0; j < TN; ++j) b[nxt][j] = Bc[(2 * (s + 1) + khalf) * LDB + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ahead of this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
     }
     if (it + 1 < n_iter) store_tiles(buf ^ 1);
     __syncthreads();
@@ -301,9 +312,13 @@ int launch_cfg(const GemmP& p, bool aligned, hipStream_t stream) {
   return OCEAN_OK;
 }
 
+inline int tuned_bk() {
+  static const int bk = [] { const char* e = getenv("OCEAN_GEMM_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
+  return bk;
+}
+
 template <bool AKM, bool BKN>
 int launch_mode(GemmP p, bool aligned, hipStream_t stream) {
-  constexpr int BK = 16;
   // tile choice: wide tiles only when they still fill the chip
   const bool big_m = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128) >= 256;
   int bm, bn;
@@ -320,9 +335,14 @@ int launch_mode(GemmP p, bool aligned, hipStream_t stream) {
     if (want < 1) want = 1;
     p.split_k = (int)want;
   }
-  if (bm == 128 && bn == 128) return launch_cfg<128, 128, BK, AKM, BKN>(p, aligned, stream);
-  if (bm == 128 && bn == 64) return launch_cfg<128, 64, BK, AKM, BKN>(p, aligned, stream);
-  return launch_cfg<64, 64, BK, AKM, BKN>(p, aligned, stream);
+  if (tuned_bk() == 32) {
+    if (bm == 128 && bn == 128) return launch_cfg<128, 128, 32, AKM, BKN>(p, aligned, stream);
+    if (bm == 128 && bn == 64) return launch_cfg<128, 64, 32, AKM, BKN>(p, aligned, stream);
+    return launch_cfg<64, 64, 32, AKM, BKN>(p, aligned, stream);
+  }
+  if (bm == 128 && bn == 128) return launch_cfg<128, 128, 16, AKM, BKN>(p, aligned, stream);
+  if (bm == 128 && bn == 64) return launch_cfg<128, 64, 16, AKM, BKN>(p, aligned, stream);
+  return launch_cfg<64, 64, 16, AKM, BKN>(p, aligned, stream);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }

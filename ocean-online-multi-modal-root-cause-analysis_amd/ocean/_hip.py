@@ -115,6 +115,7 @@ def _declare_rest(lib) -> None:
     sig("ocean_head_bwd", c_int, hp, vp, tp, vp, vp, c_size_t, vp, vp, vp, tp, vp, vp)
     sig("ocean_bce_fwd", c_int, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_bce_bwd", c_int, vp, vp, vp, c_long, c_long, vp, vp)
+    sig("ocean_conv_gemm_f32", c_int, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_int, vp)
     sig("ocean_mean_mid_f32", c_int, vp, vp, c_int, c_int, c_int, vp)
     sig("ocean_mse_fwd", c_int, vp, vp, c_long, vp, vp)
     sig("ocean_mse_bwd", c_int, vp, vp, vp, c_long, vp, vp)
