@@ -33,12 +33,17 @@ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 // so forward and backward regenerate the same mask without storing it.
 struct DropoutP { float p; uint64_t seed; };
 
+// 32-bit multiply-xorshift mixer over (seed, idx); integer multiplies run at a quarter of the fp32 rate on
+// CDNA, so the hash is kept to four of them.
 __host__ __device__ inline uint32_t ocean_hash32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  uint32_t h = (uint32_t)idx * 0x9E3779B1u + (uint32_t)seed;
+  h ^= h >> 15;
+  h += (uint32_t)(idx >> 32) * 0x85EBCA77u + (uint32_t)(seed >> 32);
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  h *= 0x297A2D39u;
+  h ^= h >> 15;
+  return h;
 }
 // multiplier applied to a surviving / dropped activation: 1/(1-p) or 0
 __host__ __device__ inline float dropout_keep(const DropoutP& d, uint64_t idx) {
@@ -75,7 +80,8 @@ struct GemmP {
   const float* R; int ldr;  // residual added elementwise, or null (R == C allowed: in-place accumulate)
   int r_bcast_T; float r_scale;  // r_bcast_T > 0: residual row is R[row / r_bcast_T] (one row per sample), times r_scale
   int relu;
-  double* colstats;         // [2][N] running (sum, sum of squares) of the pre-epilogue value, atomically accumulated, or null
+  double* colstats;         // [slots][2][N] running (sum, sum of squares) of the pre-epilogue value, atomically accumulated, or null
+  int colstat_slots;        // row-tile t adds into copy t % slots (same-address atomics serialise; the caller sums the copies)
 };
 
 int ocean_launch_gemm(const GemmP& p, hipStream_t stream);
@@ -90,6 +96,6 @@ static inline GemmP gemm_defaults() {
   p.A = p.B = nullptr; p.C = nullptr; p.M = p.N = p.K = 0; p.lda = p.ldb = p.ldc = 0;
   p.a_kmajor = 0; p.b_kn = 0; p.taps = 1; p.T = 0; p.shift0 = 0; p.shift_step = 0;
   p.tap_stride_b = 0; p.tap_stride_c = 0; p.split_k = 1; p.bias = nullptr; p.R = nullptr; p.ldr = 0; p.r_bcast_T = 0; p.r_scale = 1.f;
-  p.relu = 0; p.colstats = nullptr;
+  p.relu = 0; p.colstats = nullptr; p.colstat_slots = 1;
   return p;
 }

@@ -19,15 +19,18 @@
 namespace {
 
 constexpr int kMaxBN = 2 * OCEAN_MAX_CONV_LAYERS - 1;
+// Column statistics are accumulated with fp64 atomics; atomics on one address serialise in L2, so blocks spread
+// their partial sums over kStatSlots copies of the statistics block, which a small kernel then adds up.
+constexpr int kStatSlots = 32;
 
 struct DcnnPlan {
   int M, L, nbn, cmax;
   int width[kMaxBN], in_width[kMaxBN], is_block[kMaxBN], li[kMaxBN];
   size_t h0, u[kMaxBN], a[kMaxBN], pooled;
-  size_t stats[kMaxBN], mean[kMaxBN], invstd[kMaxBN], scale[kMaxBN], shift[kMaxBN];
+  size_t stats[kMaxBN], fslots[kMaxBN], mean[kMaxBN], invstd[kMaxBN], scale[kMaxBN], shift[kMaxBN];
   size_t wp[OCEAN_MAX_CONV_LAYERS];
   size_t fwd_total;
-  size_t gA, gB, dU, dpool, bstats[kMaxBN], dwp[OCEAN_MAX_CONV_LAYERS], bwd_total;
+  size_t gA, gB, dU, dpool, bstats[kMaxBN], bslots[kMaxBN], dwp[OCEAN_MAX_CONV_LAYERS], bwd_total;
 };
 
 inline size_t al4(size_t x) { return (x + 3) & ~size_t(3); }
@@ -63,12 +66,14 @@ int make_plan(const ocean_dcnn_shape* s, DcnnPlan* p) {
     p->stats[j] = take(4 * C);   // 2*C doubles
     p->mean[j] = take(C); p->invstd[j] = take(C); p->scale[j] = take(C); p->shift[j] = take(C);
   }
+  for (int j = 0; j < p->nbn; ++j) p->fslots[j] = take(4 * (size_t)p->width[j] * kStatSlots);
   for (int i = 0; i < s->L; ++i) p->wp[i] = take((size_t)s->kernel_size * s->channels[i] * s->channels[i]);
   p->fwd_total = o;
   o = 0;
   p->gA = take(M * p->cmax); p->gB = take(M * p->cmax); p->dU = take(M * p->cmax);
   p->dpool = take((size_t)s->B * s->channels[s->L - 1]);
   for (int j = 0; j < p->nbn; ++j) p->bstats[j] = take(4 * (size_t)p->width[j]);
+  for (int j = 0; j < p->nbn; ++j) p->bslots[j] = take(4 * (size_t)p->width[j] * kStatSlots);
   for (int i = 0; i < s->L; ++i) p->dwp[i] = take((size_t)s->kernel_size * s->channels[i] * s->channels[i]);
   p->bwd_total = o;
   return OCEAN_OK;
@@ -106,81 +111,125 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double n, c
   shift[c] = beta[c] - mu * sc;
 }
 
+// Elementwise BatchNorm kernels share one thread layout: a block is W column groups (VEC consecutive channels
+// each, W a power of two) by 256/W row lanes, so a thread keeps its channels' coefficients in registers, walks
+// down rows, and no index needs a division.  Consecutive lanes read consecutive addresses of a row; with W < 64
+// a wavefront covers several whole rows, which are contiguous too.
+struct ColTile {
+  int wlog;            // log2(W)
+  int rows;            // rows per block
+};
+inline ColTile col_tile(int C, int vec, int M, int rows_per_thread, int min_rows) {
+  const int cg = (C + vec - 1) / vec;
+  int wlog = 0;
+  while ((1 << wlog) < cg && wlog < 8) ++wlog;
+  ColTile t;
+  t.wlog = wlog;
+  t.rows = (256 >> wlog) * rows_per_thread;
+  if (t.rows < min_rows) t.rows = min_rows;
+  while ((M + t.rows - 1) / t.rows > 65535) t.rows *= 2;   // grid.y limit
+  return t;
+}
+inline dim3 col_grid(const ColTile& t, int C, int vec, int M) {
+  const int cg = (C + vec - 1) / vec;
+  return dim3(ceil_div(cg, 1 << t.wlog), ceil_div(M, t.rows));
+}
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[VEC]) {
+  if (VEC == 4) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1 % VEC] = a.y; v[2 % VEC] = a.z; v[3 % VEC] = a.w;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[VEC]) {
+  if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
+  else *p = v[0];
+}
+
 // out = dropout(relu(u*scale + shift)) (+ res)
 template <int VEC>
-__global__ void bn_apply_fwd_kernel(const float* __restrict__ u, const float* __restrict__ scale,
-                                    const float* __restrict__ shift, const float* __restrict__ res,
-                                    float* __restrict__ out, long n, int C, DropoutP dp) {
-  for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * VEC; i < n; i += (long)gridDim.x * blockDim.x * VEC) {
-    const int c = (int)(i % C);
-    if (VEC == 4) {
-      const float4 x = *reinterpret_cast<const float4*>(u + i);
-      const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-      const float4 sh = *reinterpret_cast<const float4*>(shift + c);
-      float4 y;
-      y.x = fmaxf(fmaf(x.x, sc.x, sh.x), 0.f); y.y = fmaxf(fmaf(x.y, sc.y, sh.y), 0.f);
-      y.z = fmaxf(fmaf(x.z, sc.z, sh.z), 0.f); y.w = fmaxf(fmaf(x.w, sc.w, sh.w), 0.f);
-      if (dp.p > 0.f) { y.x *= dropout_keep(dp, i); y.y *= dropout_keep(dp, i + 1); y.z *= dropout_keep(dp, i + 2); y.w *= dropout_keep(dp, i + 3); }
-      if (res) { const float4 r = *reinterpret_cast<const float4*>(res + i); y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w; }
-      *reinterpret_cast<float4*>(out + i) = y;
-    } else {
-      float y = fmaxf(fmaf(u[i], scale[c], shift[c]), 0.f);
-      if (dp.p > 0.f) y *= dropout_keep(dp, i);
-      if (res) y += res[i];
-      out[i] = y;
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ u, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ res,
+                                                           float* __restrict__ out, int M, int C, ColTile ct, DropoutP dp) {
+  const int W = 1 << ct.wlog;
+  const int tx = threadIdx.x & (W - 1), ty = threadIdx.x >> ct.wlog, RL = 256 >> ct.wlog;
+  const int c0 = (blockIdx.x * W + tx) * VEC;
+  if (c0 >= C) return;
+  const int r0 = blockIdx.y * ct.rows, r1 = min(M, r0 + ct.rows);
+  float sc[VEC], sh[VEC];
+  load_vec<VEC>(scale + c0, sc);
+  load_vec<VEC>(shift + c0, sh);
+#pragma unroll 2
+  for (int r = r0 + ty; r < r1; r += RL) {
+    const long i = (long)r * C + c0;
+    float x[VEC], y[VEC];
+    load_vec<VEC>(u + i, x);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      y[v] = fmaxf(fmaf(x[v], sc[v], sh[v]), 0.f);
+      if (dp.p > 0.f) y[v] *= dropout_keep(dp, (uint64_t)(i + v));
     }
+    if (res) {
+      float q[VEC];
+      load_vec<VEC>(res + i, q);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) y[v] += q[v];
+    }
+    store_vec<VEC>(out + i, y);
   }
 }
 
-// Column sums of g and g*xhat, g = dy * (u*scale+shift > 0), xhat = (u-mean)*invstd.
-// Block = 64 column lanes x 4 row lanes; ROWS rows per block; fp64 atomics per column.
-constexpr int kRedRows = 256;
+// Column sums of g and g*xhat, g = dy * (u*scale+shift > 0), xhat = (u-mean)*invstd; fp64 atomics per column.
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, int bcast_T, float dy_scale,
                                                             const float* __restrict__ u, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, double* __restrict__ bstats,
-                                                            int M, int C, DropoutP dp) {
-  __shared__ float red[2][4][64 * VEC];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c0 = (blockIdx.x * 64 + tx) * VEC;
-  const int r0 = blockIdx.y * kRedRows, r1 = min(M, r0 + kRedRows);
+                                                            const float* __restrict__ invstd, double* __restrict__ bslots,
+                                                            int M, int C, ColTile ct, DropoutP dp) {
+  __shared__ float red[2][256 * VEC];
+  const int W = 1 << ct.wlog;
+  const int tx = threadIdx.x & (W - 1), ty = threadIdx.x >> ct.wlog, RL = 256 >> ct.wlog;
+  const int c0 = (blockIdx.x * W + tx) * VEC;
+  const int r0 = blockIdx.y * ct.rows, r1 = min(M, r0 + ct.rows);
   float sg[VEC], sx[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) { sg[v] = 0.f; sx[v] = 0.f; }
   if (c0 < C) {
     float sc[VEC], sh[VEC], mu[VEC], is[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) { sc[v] = scale[c0 + v]; sh[v] = shift[c0 + v]; mu[v] = mean[c0 + v]; is[v] = invstd[c0 + v]; }
-    for (int r = r0 + ty; r < r1; r += 4) {
+    load_vec<VEC>(scale + c0, sc); load_vec<VEC>(shift + c0, sh);
+    load_vec<VEC>(mean + c0, mu); load_vec<VEC>(invstd + c0, is);
+#pragma unroll 4
+    for (int r = r0 + ty; r < r1; r += RL) {
       float uu[VEC], gg[VEC];
       const long ui = (long)r * C + c0;
       const long gi = bcast_T > 0 ? (long)(r / bcast_T) * C + c0 : ui;
-      if (VEC == 4) {
-        const float4 a = *reinterpret_cast<const float4*>(u + ui);
-        const float4 b = *reinterpret_cast<const float4*>(dy + gi);
-        uu[0] = a.x; uu[1 % VEC] = a.y; uu[2 % VEC] = a.z; uu[3 % VEC] = a.w;
-        gg[0] = b.x; gg[1 % VEC] = b.y; gg[2 % VEC] = b.z; gg[3 % VEC] = b.w;
-      } else { uu[0] = u[ui]; gg[0] = dy[gi]; }
+      load_vec<VEC>(u + ui, uu);
+      load_vec<VEC>(dy + gi, gg);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         float g = (fmaf(uu[v], sc[v], sh[v]) > 0.f) ? gg[v] * dy_scale : 0.f;
-        if (dp.p > 0.f) g *= dropout_keep(dp, ui + v);
+        if (dp.p > 0.f) g *= dropout_keep(dp, (uint64_t)(ui + v));
         sg[v] += g;
         sx[v] += g * (uu[v] - mu[v]) * is[v];
       }
     }
   }
+  // red[.][(ty*W + tx)*VEC + v]
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) { red[0][ty][tx * VEC + v] = sg[v]; red[1][ty][tx * VEC + v] = sx[v]; }
+  for (int v = 0; v < VEC; ++v) { red[0][threadIdx.x * VEC + v] = sg[v]; red[1][threadIdx.x * VEC + v] = sx[v]; }
   __syncthreads();
   if (ty == 0 && c0 < C) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      const float a = red[0][0][tx * VEC + v] + red[0][1][tx * VEC + v] + red[0][2][tx * VEC + v] + red[0][3][tx * VEC + v];
-      const float b = red[1][0][tx * VEC + v] + red[1][1][tx * VEC + v] + red[1][2][tx * VEC + v] + red[1][3][tx * VEC + v];
-      unsafeAtomicAdd(bstats + c0 + v, (double)a);
-      unsafeAtomicAdd(bstats + C + c0 + v, (double)b);
+      float a = 0.f, b = 0.f;
+      for (int q = 0; q < RL; ++q) { a += red[0][(q * W + tx) * VEC + v]; b += red[1][(q * W + tx) * VEC + v]; }
+      double* slot = bslots + (size_t)(blockIdx.y % kStatSlots) * 2 * C;
+      unsafeAtomicAdd(slot + c0 + v, (double)a);
+      unsafeAtomicAdd(slot + C + c0 + v, (double)b);
     }
   }
 }
@@ -188,46 +237,68 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 // du = gamma*invstd * (g - sum(g)/n - xhat*sum(g*xhat)/n)   (training)
 // du = g * scale                                            (eval: fixed statistics)
 template <int VEC>
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int bcast_T, float dy_scale, const float* __restrict__ u,
-                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const double* __restrict__ bstats, double n, float* __restrict__ du,
-                                    long total, int C, int training, DropoutP dp) {
-  for (long i = (blockIdx.x * (long)blockDim.x + threadIdx.x) * VEC; i < total; i += (long)gridDim.x * blockDim.x * VEC) {
-    const int c = (int)(i % C);
-    const long r = i / C;
-    const long gi = bcast_T > 0 ? (r / bcast_T) * C + c : i;
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int bcast_T, float dy_scale,
+                                                           const float* __restrict__ u, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const double* __restrict__ bstats,
+                                                           double n, float* __restrict__ du, int M, int C, int training,
+                                                           ColTile ct, DropoutP dp) {
+  const int W = 1 << ct.wlog;
+  const int tx = threadIdx.x & (W - 1), ty = threadIdx.x >> ct.wlog, RL = 256 >> ct.wlog;
+  const int c0 = (blockIdx.x * W + tx) * VEC;
+  if (c0 >= C) return;
+  const int r0 = blockIdx.y * ct.rows, r1 = min(M, r0 + ct.rows);
+  // per channel: du = k1*g - k0 - k2*u  with the batch terms folded (training), or k1*g (eval)
+  float sc[VEC], sh[VEC], k0[VEC], k2[VEC];
+  load_vec<VEC>(scale + c0, sc); load_vec<VEC>(shift + c0, sh);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    if (training) {
+      const float mg = (float)(bstats[c0 + v] / n), mgx = (float)(bstats[C + c0 + v] / n);
+      const float mu = mean[c0 + v], is = invstd[c0 + v];
+      // sc*(g - mg - (u-mu)*is*mgx)
+      k2[v] = sc[v] * is * mgx;
+      k0[v] = sc[v] * mg - k2[v] * mu;
+    } else {
+      k2[v] = 0.f; k0[v] = 0.f;
+    }
+  }
+#pragma unroll 2
+  for (int r = r0 + ty; r < r1; r += RL) {
     float uu[VEC], gg[VEC], o[VEC];
-    if (VEC == 4) {
-      const float4 a = *reinterpret_cast<const float4*>(u + i);
-      const float4 b = *reinterpret_cast<const float4*>(dy + gi);
-      uu[0] = a.x; uu[1 % VEC] = a.y; uu[2 % VEC] = a.z; uu[3 % VEC] = a.w;
-      gg[0] = b.x; gg[1 % VEC] = b.y; gg[2 % VEC] = b.z; gg[3 % VEC] = b.w;
-    } else { uu[0] = u[i]; gg[0] = dy[gi]; }
+    const long ui = (long)r * C + c0;
+    const long gi = bcast_T > 0 ? (long)(r / bcast_T) * C + c0 : ui;
+    load_vec<VEC>(u + ui, uu);
+    load_vec<VEC>(dy + gi, gg);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      const float sc = scale[c + v];
-      float g = (fmaf(uu[v], sc, shift[c + v]) > 0.f) ? gg[v] * dy_scale : 0.f;
-      if (dp.p > 0.f) g *= dropout_keep(dp, i + v);
-      if (training) {
-        const float mg = (float)(bstats[c + v] / n), mgx = (float)(bstats[C + c + v] / n);
-        const float xh = (uu[v] - mean[c + v]) * invstd[c + v];
-        o[v] = sc * (g - mg - xh * mgx);
-      } else {
-        o[v] = g * sc;
-      }
+      float g = (fmaf(uu[v], sc[v], sh[v]) > 0.f) ? gg[v] * dy_scale : 0.f;
+      if (dp.p > 0.f) g *= dropout_keep(dp, (uint64_t)(ui + v));
+      o[v] = fmaf(sc[v], g, -fmaf(k2[v], uu[v], k0[v]));
     }
-    if (VEC == 4) *reinterpret_cast<float4*>(du + i) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
-    else du[i] = o[0];
+    store_vec<VEC>(du + ui, o);
   }
 }
 
-__global__ void bn_bwd_param_kernel(const double* __restrict__ bstats, float* __restrict__ dgamma,
+// stats = sum of the slot copies the convolution epilogue accumulated into
+__global__ void bn_stats_collapse_kernel(const double* __restrict__ slots, double* __restrict__ stats, int n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  double s = 0.0;
+  for (int q = 0; q < kStatSlots; ++q) s += slots[(size_t)q * n + c];
+  stats[c] = s;
+}
+
+// bstats = sum of the slots; dbeta += sum(g), dgamma += sum(g*xhat)
+__global__ void bn_bwd_param_kernel(const double* __restrict__ bslots, double* __restrict__ bstats, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  if (dbeta) dbeta[c] += (float)bstats[c];
-  if (dgamma) dgamma[c] += (float)bstats[C + c];
+  double sg = 0.0, sx = 0.0;
+  for (int q = 0; q < kStatSlots; ++q) { sg += bslots[(size_t)q * 2 * C + c]; sx += bslots[(size_t)q * 2 * C + C + c]; }
+  bstats[c] = sg; bstats[C + c] = sx;
+  if (dbeta) dbeta[c] += (float)sg;
+  if (dgamma) dgamma[c] += (float)sx;
 }
 
 __global__ void mean_t_kernel(const float* __restrict__ a, float* __restrict__ out, int T, int C) {
@@ -287,13 +358,15 @@ inline DropoutP layer_dropout(const ocean_dcnn_shape* s, int j) {
 int bn_apply_fwd(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, float* ws, const float* res, hipStream_t st) {
   const int C = pl.width[j];
   const DropoutP dp = layer_dropout(s, j);
-  const long n = (long)pl.M * C;
-  if (C % 4 == 0)
-    hipLaunchKernelGGL(bn_apply_fwd_kernel<4>, dim3(egrid(n / 4)), dim3(256), 0, st, ws + pl.u[j], ws + pl.scale[j],
-                       ws + pl.shift[j], res, ws + pl.a[j], n, C, dp);
-  else
-    hipLaunchKernelGGL(bn_apply_fwd_kernel<1>, dim3(egrid(n)), dim3(256), 0, st, ws + pl.u[j], ws + pl.scale[j],
-                       ws + pl.shift[j], res, ws + pl.a[j], n, C, dp);
+  if (C % 4 == 0) {
+    const ColTile ct = col_tile(C, 4, pl.M, 8, 1);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<4>, col_grid(ct, C, 4, pl.M), dim3(256), 0, st, ws + pl.u[j], ws + pl.scale[j],
+                       ws + pl.shift[j], res, ws + pl.a[j], pl.M, C, ct, dp);
+  } else {
+    const ColTile ct = col_tile(C, 1, pl.M, 8, 1);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel<1>, col_grid(ct, C, 1, pl.M), dim3(256), 0, st, ws + pl.u[j], ws + pl.scale[j],
+                       ws + pl.shift[j], res, ws + pl.a[j], pl.M, C, ct, dp);
+  }
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }
@@ -303,7 +376,8 @@ int conv_fwd(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, const float* 
   GemmP g = gemm_defaults();
   g.A = in; g.lda = pl.in_width[j]; g.C = ws + pl.u[j]; g.ldc = pl.width[j];
   g.M = pl.M; g.N = pl.width[j]; g.K = pl.in_width[j];
-  g.colstats = s->training ? reinterpret_cast<double*>(ws + pl.stats[j]) : nullptr;
+  g.colstats = s->training ? reinterpret_cast<double*>(ws + pl.fslots[j]) : nullptr;
+  g.colstat_slots = kStatSlots;
   if (pl.is_block[j]) {
     const int i = pl.li[j], k = s->kernel_size;
     g.B = ws + pl.wp[i]; g.ldb = pl.in_width[j];
@@ -314,7 +388,14 @@ int conv_fwd(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, const float* 
   } else {
     g.B = params[pi_trans(pl.L, pl.li[j], 0)]; g.ldb = pl.in_width[j];
   }
-  return ocean_launch_gemm(g, st);
+  OCEAN_TRY(ocean_launch_gemm(g, st));
+  if (s->training) {
+    const int n2 = 2 * pl.width[j];
+    hipLaunchKernelGGL(bn_stats_collapse_kernel, dim3(ceil_div(n2, 64)), dim3(64), 0, st,
+                       reinterpret_cast<const double*>(ws + pl.fslots[j]), reinterpret_cast<double*>(ws + pl.stats[j]), n2);
+    OCEAN_LAUNCH_CHECK();
+  }
+  return OCEAN_OK;
 }
 
 const float* layer_input(const DcnnPlan& pl, int j, const float* ws) { return j == 0 ? ws + pl.h0 : ws + pl.a[j - 1]; }
@@ -413,19 +494,21 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
     const int bT = last ? s->T : 0;
     const float sc = last ? 1.0f / (float)s->T : 1.0f;
     double* bs = reinterpret_cast<double*>(wb + pl.bstats[j]);
+    double* slots = reinterpret_cast<double*>(wb + pl.bslots[j]);
+    const int min_rows = ceil_div(M, 2048);    // at most ~2048 row blocks
     if (C % 4 == 0) {
-      dim3 grid(ceil_div(C, 256), ceil_div(M, kRedRows));
-      hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, grid, dim3(256), 0, st, dy, bT, sc, wf + pl.u[j], wf + pl.scale[j],
-                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, M, C, layer_dropout(s, j));
+      const ColTile ct = col_tile(C, 4, M, 4, min_rows);
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, col_grid(ct, C, 4, M), dim3(256), 0, st, dy, bT, sc, wf + pl.u[j], wf + pl.scale[j],
+                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], slots, M, C, ct, layer_dropout(s, j));
     } else {
-      dim3 grid(ceil_div(C, 64), ceil_div(M, kRedRows));
-      hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, dim3(256), 0, st, dy, bT, sc, wf + pl.u[j], wf + pl.scale[j],
-                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, M, C, layer_dropout(s, j));
+      const ColTile ct = col_tile(C, 1, M, 4, min_rows);
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, col_grid(ct, C, 1, M), dim3(256), 0, st, dy, bT, sc, wf + pl.u[j], wf + pl.scale[j],
+                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], slots, M, C, ct, layer_dropout(s, j));
     }
     OCEAN_LAUNCH_CHECK();
     // gamma / beta gradients come from THIS rank's sums (before any cross-rank all-reduce of the block), so that
     // averaging parameter gradients over ranks yields the global-batch gradient like every other parameter
-    hipLaunchKernelGGL(bn_bwd_param_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st, bs, grads[pi_bn(pl, j, 1)], grads[pi_bn(pl, j, 2)], C);
+    hipLaunchKernelGGL(bn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, slots, bs, grads[pi_bn(pl, j, 1)], grads[pi_bn(pl, j, 2)], C);
     OCEAN_LAUNCH_CHECK();
     return OCEAN_OK;
   };
@@ -448,13 +531,15 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
     const float dsc = last ? 1.0f / (float)s->T : 1.0f;
     const double* bs = reinterpret_cast<const double*>(wb + pl.bstats[j]);
     float* dU = wb + pl.dU;
-    const long tot = (long)M * C;
-    if (C % 4 == 0)
-      hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(egrid(tot / 4)), dim3(256), 0, st, dy, bT, dsc, wf + pl.u[j], wf + pl.scale[j],
-                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, n, dU, tot, C, s->training, layer_dropout(s, j));
-    else
-      hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(egrid(tot)), dim3(256), 0, st, dy, bT, dsc, wf + pl.u[j], wf + pl.scale[j],
-                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, n, dU, tot, C, s->training, layer_dropout(s, j));
+    if (C % 4 == 0) {
+      const ColTile ct = col_tile(C, 4, M, 8, 1);
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, col_grid(ct, C, 4, M), dim3(256), 0, st, dy, bT, dsc, wf + pl.u[j], wf + pl.scale[j],
+                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, n, dU, M, C, s->training, ct, layer_dropout(s, j));
+    } else {
+      const ColTile ct = col_tile(C, 1, M, 8, 1);
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, col_grid(ct, C, 1, M), dim3(256), 0, st, dy, bT, dsc, wf + pl.u[j], wf + pl.scale[j],
+                         wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, n, dU, M, C, s->training, ct, layer_dropout(s, j));
+    }
     OCEAN_LAUNCH_CHECK();
     const float* in = layer_input(pl, j, wf);
     if (pl.is_block[j]) {

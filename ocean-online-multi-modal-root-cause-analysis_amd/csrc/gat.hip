@@ -17,6 +17,7 @@
 // backward recomputes alpha from the saved per-(node,head) max and denominator.
 #include "../../include/ocean_hip.h"
 #include "ops.h"
+#include <stdlib.h>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
@@ -140,6 +141,190 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(GatK g, const float*
     agg[node * g.HC + L.c0 + k] = acc[k] / (den[k] + 1e-16f);
     if ((L.c0 + k) % g.C == 0) { smax[node * g.H + L.hk[k]] = mx[k]; sden[node * g.H + L.hk[k]] = den[k]; }
   }
+}
+
+// ---- fast variants (H a power of two <= 16, H*C == 64*CPL) -------------------------------------------------
+// The per-edge scalar work (score, softmax weight, dropout) is done with the wave laid out as
+// (edge slot, head) = (lane / H, lane % H), 64/H edges at a time, and parked in wave-private LDS; the row
+// gathers then run as an unrolled loop whose only memory dependency is the row address read back from LDS,
+// so four 64-lane row loads are in flight at once instead of one load chain per edge.
+template <int CPL>
+__device__ __forceinline__ void load_row(const float* p, float (&v)[CPL]) {
+  if (CPL == 1) { v[0] = p[0]; }
+  else if (CPL == 2) { const float2 a = *reinterpret_cast<const float2*>(p); v[0] = a.x; v[1 % CPL] = a.y; }
+  else {
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q) {
+      const float4 a = reinterpret_cast<const float4*>(p)[q];
+      v[(4 * q) % CPL] = a.x; v[(4 * q + 1) % CPL] = a.y; v[(4 * q + 2) % CPL] = a.z; v[(4 * q + 3) % CPL] = a.w;
+    }
+  }
+}
+template <int CPL>
+__device__ __forceinline__ void store_row(float* p, const float (&v)[CPL]) {
+  if (CPL == 1) { p[0] = v[0]; }
+  else if (CPL == 2) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1 % CPL]); }
+  else {
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q)
+      reinterpret_cast<float4*>(p)[q] = make_float4(v[(4 * q) % CPL], v[(4 * q + 1) % CPL], v[(4 * q + 2) % CPL], v[(4 * q + 3) % CPL]);
+  }
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void gat_aggregate_fast_kernel(GatK g, int hlog, const float* __restrict__ Z,
+                                                                 const float* __restrict__ a_s, const float* __restrict__ a_d,
+                                                                 float* __restrict__ agg, float* __restrict__ smax,
+                                                                 float* __restrict__ sden) {
+  __shared__ float wl_all[kWavesPerBlock][64];
+  __shared__ int jl_all[kWavesPerBlock][64];
+  __shared__ float dl_all[kWavesPerBlock][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long node = (long)blockIdx.x * kWavesPerBlock + wave;
+  if (node >= (long)g.R * g.N) return;
+  float* wl = wl_all[wave]; int* jl = jl_all[wave]; float* dl = dl_all[wave];
+  const int r = (int)(node / g.N), i = (int)(node % g.N);
+  const long rbase = (long)r * g.N;
+  const int H = g.H, EPW = 64 >> hlog;
+  const int le = lane >> hlog, lh = lane & (H - 1);   // edge-role coordinates
+  const int hk = lane >> (6 - hlog), c0 = lane * CPL;  // channel-role coordinates
+  const float adl = a_d[node * H + lh];
+  const int e0 = g.rp_in[i], e1 = g.rp_in[i + 1];
+  const bool single = (e1 - e0) <= EPW;
+  float mx = -INFINITY, s_last = -INFINITY;
+  int j_last = 0;
+  for (int base = e0; base < e1; base += EPW) {
+    const int e = base + le;
+    const bool valid = e < e1;
+    const int j = valid ? g.src_in[e] : 0;
+    const float sv = valid ? lrelu(a_s[(rbase + j) * H + lh] + adl, g.slope) : -INFINITY;
+    mx = fmaxf(mx, sv);
+    s_last = sv; j_last = j;
+  }
+  for (int o = H; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float den = 0.f, acc[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
+  for (int base = e0; base < e1; base += EPW) {
+    const int e = base + le;
+    const bool valid = e < e1;
+    int j = j_last;
+    float sv = s_last;
+    if (!single) {
+      j = valid ? g.src_in[e] : 0;
+      sv = valid ? lrelu(a_s[(rbase + j) * H + lh] + adl, g.slope) : -INFINITY;
+    }
+    const float ex = valid ? __expf(sv - mx) : 0.f;
+    den += ex;
+    float w = ex;
+    if (g.att_drop.p > 0.f && valid) w *= dropout_keep(g.att_drop, ((uint64_t)r * g.E + e) * H + lh);
+    wave_lds_sync();
+    wl[lane] = w;
+    if (lh == 0) jl[le] = j;
+    wave_lds_sync();
+    const int n = min(EPW, e1 - base);
+    for (int q = 0; q < n; q += 4) {     // slots n..n+3 hold weight 0 and a valid row index
+      float zz[4][CPL], ww[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        load_row<CPL>(Z + (rbase + jl[q + u]) * g.HC + c0, zz[u]);
+        ww[u] = wl[((q + u) << hlog) + hk];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) acc[k] = fmaf(ww[u], zz[u][k], acc[k]);
+    }
+  }
+  for (int o = H; o < 64; o <<= 1) den += __shfl_xor(den, o);
+  wave_lds_sync();
+  if (le == 0) { smax[node * H + lh] = mx; sden[node * H + lh] = den; dl[lh] = den; }
+  wave_lds_sync();
+  const float inv = 1.0f / (dl[hk] + 1e-16f);
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) acc[k] *= inv;
+  store_row<CPL>(agg + node * g.HC + c0, acc);
+}
+
+template <int CPL>
+__global__ __launch_bounds__(256) void gat_bwd_source_fast_kernel(GatK g, int hlog, const float* __restrict__ Z,
+                                                                  const float* __restrict__ a_s, const float* __restrict__ a_d,
+                                                                  const float* __restrict__ smax, const float* __restrict__ sden,
+                                                                  const float* __restrict__ dagg, const float* __restrict__ Dn,
+                                                                  float* __restrict__ dZ, float* __restrict__ da_s,
+                                                                  float* __restrict__ da_d) {
+  __shared__ float wl_all[kWavesPerBlock][64];
+  __shared__ float hl_all[kWavesPerBlock][64];
+  __shared__ int il_all[kWavesPerBlock][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long node = (long)blockIdx.x * kWavesPerBlock + wave;
+  if (node >= (long)g.R * g.N) return;
+  float* wl = wl_all[wave]; float* hl = hl_all[wave]; int* il = il_all[wave];
+  const int r = (int)(node / g.N), j = (int)(node % g.N);
+  const long rbase = (long)r * g.N;
+  const int H = g.H, EPW = 64 >> hlog, LPH = 64 >> hlog;   // edges per pass; lanes per head in the channel role
+  const int le = lane >> hlog, lh = lane & (H - 1);
+  const int hk = lane >> (6 - hlog), c0 = lane * CPL;
+  float z[CPL], dz[CPL];
+  load_row<CPL>(Z + node * g.HC + c0, z);
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) dz[k] = 0.f;
+  const float asl = a_s[node * H + lh];
+  float das = 0.f;
+  const int e0 = g.rp_out[j], e1 = g.rp_out[j + 1];
+  for (int base = e0; base < e1; base += EPW) {
+    const int e = base + le;
+    const bool valid = e < e1;
+    const int i = valid ? g.dst_out[e] : j;
+    const long nh = (rbase + i) * H + lh;
+    const float raw = asl + a_d[nh];
+    const float alpha = valid ? __expf(lrelu(raw, g.slope) - smax[nh]) / (sden[nh] + 1e-16f) : 0.f;
+    float keep = 1.f;
+    if (g.att_drop.p > 0.f && valid) keep = dropout_keep(g.att_drop, ((uint64_t)r * g.E + g.eid_out[e]) * H + lh);
+    const float dnv = Dn[nh];
+    wave_lds_sync();
+    wl[lane] = alpha * keep;
+    if (lh == 0) il[le] = i;
+    wave_lds_sync();
+    const int n = min(EPW, e1 - base);
+    for (int q = 0; q < n; q += 4) {
+      float dg[4][CPL], ww[4], pr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        load_row<CPL>(dagg + (rbase + il[q + u]) * g.HC + c0, dg[u]);
+        ww[u] = wl[((q + u) << hlog) + hk];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float p = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) { dz[k] = fmaf(ww[u], dg[u][k], dz[k]); p = fmaf(dg[u][k], z[k], p); }
+        pr[u] = p;
+      }
+      for (int o = LPH >> 1; o > 0; o >>= 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pr[u] += __shfl_xor(pr[u], o);
+      }
+      if ((lane & (LPH - 1)) == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hl[((q + u) << hlog) + hk] = pr[u];
+      }
+    }
+    wave_lds_sync();
+    if (valid) {
+      const float de = alpha * (keep * hl[lane] - dnv);
+      const float ds = de * (raw > 0.f ? 1.f : g.slope);
+      das += ds;
+      unsafeAtomicAdd(da_d + nh, ds);
+    }
+  }
+  for (int o = H; o < 64; o <<= 1) das += __shfl_xor(das, o);
+  if (le == 0) da_s[node * H + lh] = das;
+  store_row<CPL>(dZ + node * g.HC + c0, dz);
 }
 
 // y = dropout(relu(headmix(agg) + bias)) (+ xin), headmix = identity (concat) or mean over heads
@@ -424,6 +609,23 @@ inline int cpl_of(const GnnPlan& p) {
     OCEAN_LAUNCH_CHECK();                                                                                 \
   } while (0)
 
+inline bool fast_edges(const GnnPlan& p) {
+  static const bool off = getenv("OCEAN_GAT_GENERIC") != nullptr;   // measurement aid: force the one-edge-at-a-time kernels
+  return !off && fast_heads(p) && cpl_of(p) * 64 == p.D && p.H <= 16;
+}
+inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+
+#define GAT_DISPATCH_FAST(KERNEL, ...)                                                                   \
+  do {                                                                                                    \
+    const int cpl__ = cpl_of(pl), hlog__ = ilog2(pl.H);                                                   \
+    const dim3 grid__(ceil_div(pl.rows, kWavesPerBlock)), block__(256);                                   \
+    if (cpl__ == 1) hipLaunchKernelGGL((KERNEL<1>), grid__, block__, 0, st, g, hlog__, __VA_ARGS__);      \
+    else if (cpl__ == 2) hipLaunchKernelGGL((KERNEL<2>), grid__, block__, 0, st, g, hlog__, __VA_ARGS__); \
+    else if (cpl__ == 4) hipLaunchKernelGGL((KERNEL<4>), grid__, block__, 0, st, g, hlog__, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<8>), grid__, block__, 0, st, g, hlog__, __VA_ARGS__);                 \
+    OCEAN_LAUNCH_CHECK();                                                                                 \
+  } while (0)
+
 // parameter table: in_w, in_b, then per layer (lin_w, att_src, att_dst, bias), then out_w, out_b
 inline int pg_layer(int l, int k) { return 2 + 4 * l + k; }
 inline int pg_out(int layers, int k) { return 2 + 4 * layers + k; }
@@ -461,7 +663,9 @@ int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features, const in
     const GatK g = make_k(s, pl, graph, l);
     OCEAN_TRY(linear_fwd(xin, D, params[pg_layer(l, 0)], nullptr, ws + pl.Z[l], D, (int)rows, D, D, 0, st));
     GAT_DISPATCH(gat_scores_kernel, g, ws + pl.Z[l], params[pg_layer(l, 1)], params[pg_layer(l, 2)], ws + pl.as_[l], ws + pl.ad[l]);
-    {
+    if (fast_edges(pl)) {
+      GAT_DISPATCH_FAST(gat_aggregate_fast_kernel, ws + pl.Z[l], ws + pl.as_[l], ws + pl.ad[l], ws + pl.agg[l], ws + pl.smax[l], ws + pl.sden[l]);
+    } else {
       const int cpl = cpl_of(pl);
       const dim3 grid(ceil_div(rows, kWavesPerBlock)), block(256);
       if (cpl == 1) hipLaunchKernelGGL(gat_aggregate_kernel<1>, grid, block, 0, st, g, ws + pl.Z[l], ws + pl.as_[l], ws + pl.ad[l], ws + pl.agg[l], ws + pl.smax[l], ws + pl.sden[l]);
@@ -510,8 +714,12 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
     else for (int h = 0; h < H; ++h) OCEAN_TRY(colsum_add(wb + pl.dagg + h * C, D, (int)rows, C, grads[pg_layer(l, 3)], st));
     GAT_DISPATCH(gat_bwd_dot_kernel, g, wb + pl.dagg, wf + pl.agg[l], wb + pl.Dn);
     OCEAN_TRY(zero_f32(wb + pl.dad, rows * H, st));
-    GAT_DISPATCH(gat_bwd_source_kernel, g, wf + pl.Z[l], wf + pl.as_[l], wf + pl.ad[l], wf + pl.smax[l], wf + pl.sden[l],
-                 wb + pl.dagg, wb + pl.Dn, wb + pl.dZ, wb + pl.das, wb + pl.dad);
+    if (fast_edges(pl))
+      GAT_DISPATCH_FAST(gat_bwd_source_fast_kernel, wf + pl.Z[l], wf + pl.as_[l], wf + pl.ad[l], wf + pl.smax[l], wf + pl.sden[l],
+                        wb + pl.dagg, wb + pl.Dn, wb + pl.dZ, wb + pl.das, wb + pl.dad);
+    else
+      GAT_DISPATCH(gat_bwd_source_kernel, g, wf + pl.Z[l], wf + pl.as_[l], wf + pl.ad[l], wf + pl.smax[l], wf + pl.sden[l],
+                   wb + pl.dagg, wb + pl.Dn, wb + pl.dZ, wb + pl.das, wb + pl.dad);
     hipLaunchKernelGGL(gat_bwd_att_param_kernel, dim3(ceil_div(D, 64), ceil_div(rows, kAttRows)), dim3(64), 0, st, wf + pl.Z[l],
                        wb + pl.das, wb + pl.dad, grads[pg_layer(l, 1)], grads[pg_layer(l, 2)], rows, H, C);
     OCEAN_LAUNCH_CHECK();

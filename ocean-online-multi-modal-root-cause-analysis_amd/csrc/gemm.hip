@@ -263,8 +263,9 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmP p) {
       s += __shfl_xor(s, 32);
       q += __shfl_xor(q, 32);
       if (lane < 32 && col_ok) {
-        unsafeAtomicAdd(p.colstats + col, (double)s);
-        unsafeAtomicAdd(p.colstats + p.N + col, (double)q);
+        double* cs = p.colstats + (size_t)(tile_m % p.colstat_slots) * 2 * p.N;
+        unsafeAtomicAdd(cs + col, (double)s);
+        unsafeAtomicAdd(cs + p.N + col, (double)q);
       }
     }
     const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
@@ -354,6 +355,7 @@ int ocean_launch_gemm(const GemmP& p, hipStream_t stream) {
   if (!p.A || !p.B || !p.C) return OCEAN_ERR_NULL;
   if (p.a_kmajor && !p.b_kn) return OCEAN_ERR_UNSUPPORTED;
   if (p.taps > 1 && p.T <= 0) return OCEAN_ERR_BAD_SHAPE;
+  if (p.colstats && p.colstat_slots < 1) return OCEAN_ERR_BAD_SHAPE;
   // vector (16-byte) loads need every row start and every in-range 4-group aligned
   bool aligned = al16(p.A) && al16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0 &&
                  p.tap_stride_b % 4 == 0;

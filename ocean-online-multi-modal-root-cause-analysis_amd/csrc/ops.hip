@@ -30,30 +30,43 @@ int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float*
 
 namespace {
 
-// Each block reduces ROWS rows of up to 256 columns; threads run along columns
-// (coalesced row reads), one atomic per column per block.
-// Block = 64 column lanes x 4 row lanes over kColsumRows rows: each wave reads 256 contiguous bytes per row,
-// four independent accumulators per thread keep loads in flight; one atomic per column per block.
-constexpr int kColsumRows = 1024;
-
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int lda, int M, int N, float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + tx;
-  const int r0 = blockIdx.y * kColsumRows;
-  const int r1 = min(M, r0 + kColsumRows);
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (col < N) {
-    int r = r0 + ty;
-    for (; r + 12 < r1; r += 16) {
-      s0 += a[(long)r * lda + col]; s1 += a[(long)(r + 4) * lda + col];
-      s2 += a[(long)(r + 8) * lda + col]; s3 += a[(long)(r + 12) * lda + col];
+// Column sums: a block is W column groups (VEC consecutive columns each, W a power of two) by 256/W row lanes
+// over `rows` rows; consecutive lanes read consecutive addresses, eight rows are in flight per thread, and each
+// block issues one atomic per column.
+template <int VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int lda, int M, int N, float* __restrict__ out,
+                                                     int wlog, int rows) {
+  __shared__ float red[256 * VEC];
+  const int W = 1 << wlog, RL = 256 >> wlog;
+  const int tx = threadIdx.x & (W - 1), ty = threadIdx.x >> wlog;
+  const int c0 = (blockIdx.x * W + tx) * VEC;
+  const int r0 = blockIdx.y * rows, r1 = min(M, r0 + rows);
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  if (c0 < N) {
+#pragma unroll 8
+    for (int r = r0 + ty; r < r1; r += RL) {
+      const float* p = a + (long)r * lda + c0;
+      if (VEC == 4) {
+        const float4 x = *reinterpret_cast<const float4*>(p);
+        acc[0] += x.x; acc[1 % VEC] += x.y; acc[2 % VEC] += x.z; acc[3 % VEC] += x.w;
+      } else {
+        acc[0] += *p;
+      }
     }
-    for (; r < r1; r += 4) s0 += a[(long)r * lda + col];
   }
-  red[ty][tx] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) red[threadIdx.x * VEC + v] = acc[v];
   __syncthreads();
-  if (ty == 0 && col < N) unsafeAtomicAdd(out + col, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+  if (ty == 0 && c0 < N) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float t = 0.f;
+      for (int q = 0; q < RL; ++q) t += red[(q * W + tx) * VEC + v];
+      unsafeAtomicAdd(out + c0 + v, t);
+    }
+  }
 }
 
 __global__ void relu_bwd_kernel(float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy, int M, int N) {
@@ -89,8 +102,18 @@ inline int grid_for(long n, int block = 256, int cap = 4096) {
 
 int colsum_add(const float* a, int lda, int M, int N, float* out, hipStream_t s) {
   if (M <= 0 || N <= 0) return OCEAN_ERR_BAD_SHAPE;
-  dim3 grid(ceil_div(N, 64), ceil_div(M, kColsumRows));
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, a, lda, M, N, out);
+  const bool v4 = (N % 4 == 0) && (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+  const int vec = v4 ? 4 : 1;
+  const int cg = (N + vec - 1) / vec;
+  int wlog = 0;
+  while ((1 << wlog) < cg && wlog < 8) ++wlog;
+  const int RL = 256 >> wlog;
+  // Same-address atomics serialise at the memory side (~tens of ns each): keep them to <= 256 per column.
+  int rows = RL * 4;
+  if (rows < ceil_div(M, 256)) rows = ceil_div(M, 256);
+  dim3 grid(ceil_div(cg, 1 << wlog), ceil_div(M, rows));
+  if (v4) hipLaunchKernelGGL(colsum_kernel<4>, grid, dim3(256), 0, s, a, lda, M, N, out, wlog, rows);
+  else hipLaunchKernelGGL(colsum_kernel<1>, grid, dim3(256), 0, s, a, lda, M, N, out, wlog, rows);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }

@@ -74,7 +74,8 @@ def test_default_architecture_fixture(golden):
 
 
 @pytest.mark.parametrize("B,T_,ch,dil,k", [(4, 33, [16, 32], [1, 2], 3), (2, 64, [64, 128, 256, 512], [1, 2, 4, 8], 3),
-                                            (3, 5, [12, 20], [2, 4], 5), (1, 2, [8], [1], 3), (5, 9, [6, 10], [1, 3], 1)])
+                                            (3, 5, [12, 20], [2, 4], 5), (1, 2, [8], [1], 3), (5, 9, [6, 10], [1, 3], 1),
+                                            (3, 50, [7, 13], [1, 2], 3), (2, 300, [1028], [2], 3)])
 def test_against_oracle_random(B, T_, ch, dil, k):
     from ocean.models.components import DilatedCNN
     torch.manual_seed(0)
@@ -132,3 +133,36 @@ def test_dropout_statistics_and_backward_mask():
     y2 = m(x.detach())
     assert not torch.equal(y, y2)
     assert abs(float(y.mean()) - float(y2.mean())) < 0.02 * abs(float(y.mean())) + 1e-3
+
+
+@pytest.mark.parametrize("ch", [[16, 32], [7, 10]])
+def test_dropout_backward_matches_finite_differences(ch):
+    """Under a fixed mask seed the training-mode forward (batch statistics + dropout) is a deterministic function;
+    its central-difference directional derivative must agree with the analytic gradient, which it only does when
+    the backward kernels regenerate the forward's masks."""
+    from ocean.models.components import DilatedCNN
+    m = DilatedCNN(5, ch, 3, [1, 2], dropout=0.2, output_dim=6)
+    m.load_state_dict(synth.fill_state_dict(m.state_dict(), 8))
+    m = m.cuda().train()
+    x = torch.randn(6, 40, 5, generator=torch.Generator().manual_seed(1)).cuda()
+    gw = torch.randn(6, 6, generator=torch.Generator().manual_seed(2)).cuda()
+    params = list(m.parameters())
+    gen = torch.Generator().manual_seed(3)
+    dirs = [torch.randn(p.shape, generator=gen).cuda() * p.detach().abs().mean().clamp_min(1e-3) for p in params]
+
+    def f():
+        torch.manual_seed(31)
+        return (m(x).double() * gw.double()).sum()
+
+    f().backward()
+    analytic = sum((p.grad.double() * d.double()).sum() for p, d in zip(params, dirs)).item()
+    eps = 1e-2
+    with torch.no_grad():
+        for p, d in zip(params, dirs):
+            p.add_(d, alpha=eps)
+        fp = f().item()
+        for p, d in zip(params, dirs):
+            p.add_(d, alpha=-2 * eps)
+        fm = f().item()
+    numeric = (fp - fm) / (2 * eps)
+    assert abs(numeric - analytic) <= 5e-2 * max(abs(analytic), abs(numeric)) + 1e-3, (numeric, analytic)

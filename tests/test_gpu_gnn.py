@@ -36,6 +36,11 @@ CASES = [  # N, G, D, H, layers, B, avg_deg
     (40, 12, 128, 1, 2, 2, 5.0),   # one head: last layer keeps width -> residual on the pooled layer
     (300, 12, 128, 4, 1, 2, 8.0),
     (17, 3, 24, 3, 2, 2, 2.0),     # odd head count
+    (64, 12, 128, 4, 2, 2, 24.0),  # in/out degrees above 16: several edge chunks per node in the edge-parallel kernels
+    (48, 6, 64, 16, 2, 2, 10.0),   # 16 heads: 4 edges per chunk
+    (40, 12, 64, 1, 2, 2, 5.0),    # one head, one channel per lane
+    (32, 8, 256, 8, 2, 2, 6.0),    # 4 channels per lane
+    (24, 8, 512, 4, 1, 2, 5.0),    # 8 channels per lane
 ]
 
 
@@ -108,3 +113,39 @@ def test_dropout_replicas_differ_and_stay_finite():
     with torch.no_grad():
         ye = m.forward_graph(nf, g, 8)
     assert torch.equal(ye[0], ye[7])
+
+
+@pytest.mark.parametrize("D,H,deg", [(128, 4, 20.0), (64, 16, 6.0), (24, 3, 3.0)])
+def test_dropout_backward_matches_finite_differences(D, H, deg):
+    """With dropout on, forward and backward must regenerate the same masks: under a fixed seed the forward is a
+    deterministic function of the parameters, and its directional derivative (central differences) must agree
+    with the analytic gradient."""
+    from ocean.models.components import DeviceGraph, GraphNeuralNetwork
+    N, B = 48, 3
+    m = GraphNeuralNetwork(12, D, 2, H, dropout=0.3, batch_norm=False)
+    m.load_state_dict(synth.fill_state_dict(m.state_dict(), 5))
+    m = m.cuda().train()
+    g = DeviceGraph.from_adjacency(synth.random_digraph(N, deg, 9), "cuda")
+    nf = torch.randn(N, 12, generator=torch.Generator().manual_seed(1)).cuda()
+    gw = torch.randn(B, D, generator=torch.Generator().manual_seed(2)).cuda()
+    names = [n for n, _ in m.named_parameters()]
+    params = [p for p in m.parameters()]
+
+    def f():
+        torch.manual_seed(77)                      # the component draws its mask seed from torch's CPU generator
+        return (m.forward_graph(nf, g, B).double() * gw.double()).sum()
+
+    f().backward()
+    grads = [p.grad.clone() for p in params]
+    eps = 3e-3
+    for name, p, gr in zip(names, params, grads):   # one parameter tensor at a time: ReLU kinks keep the step small
+        d = torch.randn(p.shape, generator=torch.Generator().manual_seed(3)).cuda() * p.detach().abs().mean().clamp_min(1e-3)
+        analytic = (gr.double() * d.double()).sum().item()
+        with torch.no_grad():
+            p.add_(d, alpha=eps)
+            fp = f().item()
+            p.add_(d, alpha=-2 * eps)
+            fm = f().item()
+            p.add_(d, alpha=eps)
+        numeric = (fp - fm) / (2 * eps)
+        assert abs(numeric - analytic) <= 5e-2 * abs(analytic) + 3e-3, (name, numeric, analytic)
