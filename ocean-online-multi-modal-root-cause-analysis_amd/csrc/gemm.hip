@@ -14,8 +14,8 @@
 // conflict-free ds_read_b32 per lane (lane l reads element [k=2s+(l>>5)][l&31]).
 // Tiles whose global storage is k-contiguous are transposed on the LDS write;
 // the row pad (32/BK floats) makes those scattered writes conflict-free.
-// Global loads for tile i+1 are issued before the MFMAs of tile i (register
-// prefetch) and written to the other LDS buffer afterwards: one barrier per tile.
+// Global loads run two tiles ahead of the MFMAs through registers into a ring of
+// three LDS tiles, with one barrier per tile placed mid-tile (see the main loop).
 #include "common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kRing = 3;      // LDS tiles in flight per operand
 
 __device__ __forceinline__ int xcd_swizzle(int orig, int nwg) {
   // Blocks b and b+8 share an XCD (round-robin dispatch).  Give each XCD a
@@ -45,9 +46,9 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmP p) {
   constexpr int A_F4 = BM * BK / 4 / kThreads;
   constexpr int B_F4 = BN * BK / 4 / kThreads;
   static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for 256 threads");
-  __shared__ __align__(16) float smem[2 * BK * (LDA + LDB)];
+  __shared__ __align__(16) float smem[kRing * BK * (LDA + LDB)];
   float* As = smem;
-  float* Bs = smem + 2 * BK * LDA;
+  float* Bs = smem + kRing * BK * LDA;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -76,126 +77,186 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmP p) {
 
   // per-thread load coordinates that do not change over the reduction
   int a_row[A_F4], a_col[A_F4], a_t[A_F4];
-  int b_row[B_F4], b_col[B_F4], b_t[B_F4];
+  int b_row[B_F4], b_col[B_F4];
+  unsigned a_voff[A_F4], b_voff[B_F4];   // loop-invariant part of the byte offset (ALIGNED path)
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) {
     const int idx = tid + i * kThreads;
-    if (AKM) { a_row[i] = idx / (BM / 4); a_col[i] = (idx % (BM / 4)) * 4; a_t[i] = 0; }
-    else {
+    if (AKM) {
+      a_row[i] = idx / (BM / 4); a_col[i] = (idx % (BM / 4)) * 4; a_t[i] = 0;
+      a_voff[i] = (unsigned)(a_row[i] * p.lda + m0 + a_col[i]) * 4u;
+    } else {
       a_row[i] = idx / (BK / 4); a_col[i] = (idx % (BK / 4)) * 4;
       a_t[i] = (p.T > 0) ? (m0 + a_row[i]) % p.T : 0;
+      a_voff[i] = (unsigned)a_col[i] * 4u;
     }
   }
 #pragma unroll
   for (int i = 0; i < B_F4; ++i) {
     const int idx = tid + i * kThreads;
-    if (BKN) { b_row[i] = idx / (BN / 4); b_col[i] = (idx % (BN / 4)) * 4; }
-    else { b_row[i] = idx / (BK / 4); b_col[i] = (idx % (BK / 4)) * 4; }
-    b_t[i] = 0;
+    if (BKN) {
+      b_row[i] = idx / (BN / 4); b_col[i] = (idx % (BN / 4)) * 4;
+      b_voff[i] = (unsigned)(b_row[i] * p.ldb + n0 + b_col[i]) * 4u;
+    } else {
+      b_row[i] = idx / (BK / 4); b_col[i] = (idx % (BK / 4)) * 4;
+      b_voff[i] = (unsigned)((n0 + b_row[i]) * p.ldb + b_col[i]) * 4u;
+    }
   }
 
   float4 ra[A_F4], rb[B_F4];
 
-  auto load_tiles = [&](int it) {
-    const int tap = AKM ? ztap : it / nk;
-    const int kk0 = k_begin + (it % nk) * BK;
-    const int shift = (p.T > 0) ? p.shift0 + tap * p.shift_step : 0;
-    // ---- A
-#pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  // One "piece" = one float4 per thread of one operand; a tile is A_F4 + B_F4 pieces.  Pieces are loaded and
+  // stored one at a time so that the main loop can spread them over the MFMA k-steps.
+  // ALIGNED operands are read with raw buffer loads: a lane that must read zero (outside the matrix, outside the
+  // sample's time window, or a tile past the end of the reduction) gets an out-of-range offset instead of a
+  // branch, so the loop body is straight-line and the compiler can count outstanding loads (vmcnt(N)) across it.
+  // The wave-uniform part of an address travels in the scalar offset (never negative).
+  constexpr unsigned kOob = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, 0x7FFFFFF0, 0x00020000);
+  auto buf_load = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, int soff) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, soff, 0);
+    const unsigned x = r[0], y = r[1], z = r[2], w = r[3];   // (bit_cast applied to a vector element reads element 0)
+    return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
+  };
+
+  // wave-uniform description of reduction tile `it`
+  struct TileAt { int tap, kk0, shift, kt; bool valid; };
+  const unsigned t_lim = p.T > 0 ? (unsigned)p.T : 0x7FFFFFFFu;
+  auto tile_at = [&](int it) {
+    TileAt t;
+    t.tap = AKM ? ztap : it / nk;
+    t.kk0 = k_begin + (it % nk) * BK;
+    t.shift = (p.T > 0) ? p.shift0 + t.tap * p.shift_step : 0;
+    t.kt = (AKM && p.T > 0) ? t.kk0 % p.T : 0;
+    t.valid = it < n_iter;
+    return t;
+  };
+
+  auto load_a = [&](const TileAt& t, int i) {
+    if (ALIGNED) {
+      if (AKM) {
+        const bool ok = t.valid && t.kk0 + a_row[i] < k_end && m0 + a_col[i] < p.M;
+        ra[i] = buf_load(rsrc_a, ok ? a_voff[i] : kOob, t.kk0 * p.lda * 4);
+      } else {
+        const int gm = m0 + a_row[i];
+        const bool ok = t.valid && gm < p.M && t.kk0 + a_col[i] < k_end && (unsigned)(a_t[i] + t.shift) < t_lim;
+        const unsigned off = (unsigned)((gm + t.shift) * p.lda) * 4u + a_voff[i];
+        ra[i] = buf_load(rsrc_a, ok ? off : kOob, t.kk0 * 4);
+      }
+      return;
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t.valid) {
       if (AKM) {                       // stored [k][m]: vector along m
-        const int gk = kk0 + a_row[i], gm = m0 + a_col[i];
+        const int gk = t.kk0 + a_row[i], gm = m0 + a_col[i];
         if (gk < k_end) {
           const float* src = p.A + (long)gk * p.lda + gm;
-          if (ALIGNED) { if (gm < p.M) v = *reinterpret_cast<const float4*>(src); }
-          else {
-            if (gm + 0 < p.M) v.x = src[0];
-            if (gm + 1 < p.M) v.y = src[1];
-            if (gm + 2 < p.M) v.z = src[2];
-            if (gm + 3 < p.M) v.w = src[3];
-          }
+          if (gm + 0 < p.M) v.x = src[0];
+          if (gm + 1 < p.M) v.y = src[1];
+          if (gm + 2 < p.M) v.z = src[2];
+          if (gm + 3 < p.M) v.w = src[3];
         }
       } else {                         // stored [m][k]: vector along k, row-shifted
-        const int gm = m0 + a_row[i], gk = kk0 + a_col[i];
-        const bool ok = gm < p.M && (p.T == 0 || (unsigned)(a_t[i] + shift) < (unsigned)p.T);
+        const int gm = m0 + a_row[i], gk = t.kk0 + a_col[i];
+        const bool ok = gm < p.M && (unsigned)(a_t[i] + t.shift) < t_lim;
         if (ok) {
-          const float* src = p.A + (long)(gm + shift) * p.lda + gk;
-          if (ALIGNED) { if (gk < k_end) v = *reinterpret_cast<const float4*>(src); }
-          else {
-            if (gk + 0 < k_end) v.x = src[0];
-            if (gk + 1 < k_end) v.y = src[1];
-            if (gk + 2 < k_end) v.z = src[2];
-            if (gk + 3 < k_end) v.w = src[3];
-          }
+          const float* src = p.A + (long)(gm + t.shift) * p.lda + gk;
+          if (gk + 0 < k_end) v.x = src[0];
+          if (gk + 1 < k_end) v.y = src[1];
+          if (gk + 2 < k_end) v.z = src[2];
+          if (gk + 3 < k_end) v.w = src[3];
         }
       }
-      ra[i] = v;
     }
-    // ---- B
-    const float* Bt = p.B + (AKM ? 0 : (long)tap * p.tap_stride_b);
-#pragma unroll
-    for (int i = 0; i < B_F4; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    ra[i] = v;
+  };
+  auto load_b = [&](const TileAt& t, int i) {
+    // time index of reduction row gk when the reduction runs over (sample, time) rows
+    auto row_time = [&](int i2) {
+      int tt = t.kt + b_row[i2];
+      if (p.T >= BK) tt = tt >= p.T ? tt - p.T : tt;
+      else if (p.T > 0) tt %= p.T;
+      return tt;
+    };
+    if (ALIGNED) {
+      if (BKN && AKM) {
+        const int gk = t.kk0 + b_row[i];
+        const bool ok = t.valid && gk < k_end && n0 + b_col[i] < p.N && (unsigned)(row_time(i) + t.shift) < t_lim;
+        const unsigned off = (unsigned)((gk + t.shift) * p.ldb + n0 + b_col[i]) * 4u;
+        rb[i] = buf_load(rsrc_b, ok ? off : kOob, 0);
+      } else if (BKN) {
+        const bool ok = t.valid && t.kk0 + b_row[i] < k_end && n0 + b_col[i] < p.N;
+        rb[i] = buf_load(rsrc_b, ok ? b_voff[i] : kOob, (int)(t.tap * p.tap_stride_b + (long)t.kk0 * p.ldb) * 4);
+      } else {
+        const bool ok = t.valid && n0 + b_row[i] < p.N && t.kk0 + b_col[i] < k_end;
+        rb[i] = buf_load(rsrc_b, ok ? b_voff[i] : kOob, (int)(t.tap * p.tap_stride_b + t.kk0) * 4);
+      }
+      return;
+    }
+    const float* Bt = p.B + (AKM ? 0 : (long)t.tap * p.tap_stride_b);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t.valid) {
       if (BKN) {                       // stored [k][n]: vector along n; rows shifted only when reducing over rows
-        const int gk = kk0 + b_row[i], gn = n0 + b_col[i];
+        const int gk = t.kk0 + b_row[i], gn = n0 + b_col[i];
         bool ok = gk < k_end;
         int srow = gk;
         if (AKM && p.T > 0) {
-          const int t = gk % p.T;
-          ok = ok && (unsigned)(t + shift) < (unsigned)p.T;
-          srow = gk + shift;
+          ok = ok && (unsigned)(row_time(i) + t.shift) < (unsigned)p.T;
+          srow = gk + t.shift;
         }
         if (ok) {
           const float* src = Bt + (long)srow * p.ldb + gn;
-          if (ALIGNED) { if (gn < p.N) v = *reinterpret_cast<const float4*>(src); }
-          else {
-            if (gn + 0 < p.N) v.x = src[0];
-            if (gn + 1 < p.N) v.y = src[1];
-            if (gn + 2 < p.N) v.z = src[2];
-            if (gn + 3 < p.N) v.w = src[3];
-          }
+          if (gn + 0 < p.N) v.x = src[0];
+          if (gn + 1 < p.N) v.y = src[1];
+          if (gn + 2 < p.N) v.z = src[2];
+          if (gn + 3 < p.N) v.w = src[3];
         }
       } else {                         // stored [n][k]: vector along k
-        const int gn = n0 + b_row[i], gk = kk0 + b_col[i];
+        const int gn = n0 + b_row[i], gk = t.kk0 + b_col[i];
         if (gn < p.N) {
           const float* src = Bt + (long)gn * p.ldb + gk;
-          if (ALIGNED) { if (gk < k_end) v = *reinterpret_cast<const float4*>(src); }
-          else {
-            if (gk + 0 < k_end) v.x = src[0];
-            if (gk + 1 < k_end) v.y = src[1];
-            if (gk + 2 < k_end) v.z = src[2];
-            if (gk + 3 < k_end) v.w = src[3];
-          }
+          if (gk + 0 < k_end) v.x = src[0];
+          if (gk + 1 < k_end) v.y = src[1];
+          if (gk + 2 < k_end) v.z = src[2];
+          if (gk + 3 < k_end) v.w = src[3];
         }
       }
-      rb[i] = v;
+    }
+    rb[i] = v;
+  };
+  auto store_a = [&](int buf, int i) {
+    float* Ad = As + buf * BK * LDA;
+    if (AKM) *reinterpret_cast<float4*>(Ad + a_row[i] * LDA + a_col[i]) = ra[i];
+    else {
+      Ad[(a_col[i] + 0) * LDA + a_row[i]] = ra[i].x;
+      Ad[(a_col[i] + 1) * LDA + a_row[i]] = ra[i].y;
+      Ad[(a_col[i] + 2) * LDA + a_row[i]] = ra[i].z;
+      Ad[(a_col[i] + 3) * LDA + a_row[i]] = ra[i].w;
     }
   };
-
-  auto store_tiles = [&](int buf) {
-    float* Ad = As + buf * BK * LDA;
+  auto store_b = [&](int buf, int i) {
     float* Bd = Bs + buf * BK * LDB;
-#pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-      if (AKM) *reinterpret_cast<float4*>(Ad + a_row[i] * LDA + a_col[i]) = ra[i];
-      else {
-        Ad[(a_col[i] + 0) * LDA + a_row[i]] = ra[i].x;
-        Ad[(a_col[i] + 1) * LDA + a_row[i]] = ra[i].y;
-        Ad[(a_col[i] + 2) * LDA + a_row[i]] = ra[i].z;
-        Ad[(a_col[i] + 3) * LDA + a_row[i]] = ra[i].w;
-      }
+    if (BKN) *reinterpret_cast<float4*>(Bd + b_row[i] * LDB + b_col[i]) = rb[i];
+    else {
+      Bd[(b_col[i] + 0) * LDB + b_row[i]] = rb[i].x;
+      Bd[(b_col[i] + 1) * LDB + b_row[i]] = rb[i].y;
+      Bd[(b_col[i] + 2) * LDB + b_row[i]] = rb[i].z;
+      Bd[(b_col[i] + 3) * LDB + b_row[i]] = rb[i].w;
     }
+  };
+  auto load_tiles = [&](int it) {
+    const TileAt t = tile_at(it);
 #pragma unroll
-    for (int i = 0; i < B_F4; ++i) {
-      if (BKN) *reinterpret_cast<float4*>(Bd + b_row[i] * LDB + b_col[i]) = rb[i];
-      else {
-        Bd[(b_col[i] + 0) * LDB + b_row[i]] = rb[i].x;
-        Bd[(b_col[i] + 1) * LDB + b_row[i]] = rb[i].y;
-        Bd[(b_col[i] + 2) * LDB + b_row[i]] = rb[i].z;
-        Bd[(b_col[i] + 3) * LDB + b_row[i]] = rb[i].w;
-      }
-    }
+    for (int i = 0; i < A_F4; ++i) load_a(t, i);
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) load_b(t, i);
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) store_a(buf, i);
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) store_b(buf, i);
   };
 
   f32x16 acc[TM][TN];
@@ -206,44 +267,77 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Software pipeline over a ring of three LDS tiles.  While tile `it` is multiplied, the registers holding tile
+  // it+1 (loaded one iteration earlier) are written to the next ring slot, the global loads of tile it+2 are issued
+  // into the freed registers, and - after the single barrier in the middle of the iteration - the first fragments
+  // of tile it+1 are read, so the matrix pipe never waits on a load, an LDS write or a fragment read at an
+  // iteration boundary.  Ring slot (it+1)%3 was last read as tile it-2, which every wave finished before it
+  // passed the barrier of iteration it-1.
   load_tiles(0);
   store_tiles(0);
+  load_tiles(1);
   __syncthreads();
 
   const int a_frag = wm * (BM / 2) + (lane & 31);
   const int b_frag = wn * (BN / 2) + (lane & 31);
   const int khalf = lane >> 5;
+  constexpr int KS = BK / 2;          // MFMA k-steps per tile (even, so the fragment double buffer lines up)
+  static_assert(KS % 2 == 0 && KS >= 4, "tile depth");
+  constexpr int PPS = (A_F4 + B_F4 + KS / 2 - 1) / (KS / 2);   // staging pieces per k-step of the first half-tile
 
+  float a[2][TM], b[2][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) a[0][i] = As[khalf * LDA + a_frag + i * 32];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b[0][j] = Bs[khalf * LDB + b_frag + j * 32];
+
+  int buf = 0;
   for (int it = 0; it < n_iter; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < n_iter) load_tiles(it + 1);
+    const int nbuf = (buf + 1 == kRing) ? 0 : buf + 1;
     const float* Ac = As + buf * BK * LDA + a_frag;
     const float* Bc = Bs + buf * BK * LDB + b_frag;
-    // fragments of k-step s+1 are read from LDS before the MFMAs of step s issue, so the LDS latency
-    // hides behind 4 x 64 cycles of matrix work instead of stalling every step
-    float a[2][TM], b[2][TN];
+    const float* An = As + nbuf * BK * LDA + a_frag;
+    const float* Bn = Bs + nbuf * BK * LDB + b_frag;
+    const bool more = it + 1 < n_iter;
+    const TileAt t2 = tile_at(it + 2);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[0][i] = Ac[khalf * LDA + i * 32];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b[0][j] = Bc[khalf * LDB + j * 32];
-#pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
+    for (int s = 0; s < KS; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
-      if (s + 1 < BK / 2) {
+      if (s + 1 < KS) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[nxt][i] = Ac[(2 * (s + 1) + khalf) * LDA + i * 32];
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[nxt][j] = Bc[(2 * (s + 1) + khalf) * LDB + j * 32];
+      } else if (more) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[nxt][i] = An[khalf * LDA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[nxt][j] = Bn[khalf * LDB + j * 32];
       }
-      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ahead of this step's MFMAs
+      __builtin_amdgcn_sched_barrier(0);      // keep the fragment prefetch ahead of this step's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      // staging work of this k-step, issued behind its MFMAs: piece q of tile it+1 goes from registers to the next
+      // ring slot and the same registers are reloaded with piece q of tile it+2 (a full iteration ahead of its use)
+      if (s < KS / 2) {
+#pragma unroll
+        for (int q = s * PPS; q < (s + 1) * PPS; ++q) {
+          if (q < A_F4) {
+            store_a(nbuf, q);
+            load_a(t2, q);
+          } else if (q < A_F4 + B_F4) {
+            store_b(nbuf, q - A_F4);
+            load_b(t2, q - A_F4);
+          }
+        }
+      }
+      if (s == KS / 2) __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (it + 1 < n_iter) store_tiles(buf ^ 1);
-    __syncthreads();
+    buf = nbuf;
   }
 
   // ------------------------------------------------------------ epilogue
@@ -306,44 +400,49 @@ int launch_cfg(const GemmP& p, bool aligned, hipStream_t stream) {
     const double bytes = 4.0 * ((double)p.M * p.K * (AKM ? 1 : 1) + (double)p.N * p.K * p.taps + (double)p.M * p.N * (AKM ? p.taps : 1));
     ocean_prof_begin(name, flops, bytes, stream, &tok);
   }
-  if (aligned) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, true>), grid, dim3(kThreads), 0, stream, p);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, false>), grid, dim3(kThreads), 0, stream, p);
+  static const int dyn_lds = [] { const char* e = getenv("OCEAN_GEMM_DYNLDS"); return e ? atoi(e) : 0; }();   // occupancy experiments
+  if (aligned) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, true>), grid, dim3(kThreads), dyn_lds, stream, p);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, false>), grid, dim3(kThreads), dyn_lds, stream, p);
   ocean_prof_end(tok, stream);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }
 
-inline int tuned_bk() {
-  static const int bk = [] { const char* e = getenv("OCEAN_GEMM_BK"); return (e && atoi(e) == 32) ? 32 : 16; }();
-  return bk;
+inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
+// development knobs (read once): OCEAN_GEMM_SMALL_BK (k-depth of the 64x64 tiles), OCEAN_GEMM_WG_CHUNK (minimum
+// reduction rows per block of a split row reduction), OCEAN_GEMM_WG_BIGK (row reductions at least this long use
+// 128x128 tiles)
+inline int small_bk() { static const int v = env_int("OCEAN_GEMM_SMALL_BK", 16) == 32 ? 32 : 16; return v; }
+inline int wg_chunk() { static const int v = env_int("OCEAN_GEMM_WG_CHUNK", 256); return v < 16 ? 16 : v; }
+inline long wg_big_k() { static const int v = env_int("OCEAN_GEMM_WG_BIGK", 8192); return v; }
 
 template <bool AKM, bool BKN>
 int launch_mode(GemmP p, bool aligned, hipStream_t stream) {
   // tile choice: wide tiles only when they still fill the chip
   const bool big_m = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128) >= 256;
   int bm, bn;
-  if (AKM && p.M >= 128 && p.N >= 128) { bm = 128; bn = 128; }      // row reductions fill the chip through split-K
-  else if (p.N > 64 && big_m) { bm = 128; bn = 128; }
-  else if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 256) { bm = 128; bn = 64; }
+  if (AKM && p.M >= 128 && p.N >= 128 && p.K >= wg_big_k()) { bm = 128; bn = 128; }   // long row reductions fill the chip through split-K
+  else if (!AKM && p.N > 64 && big_m) { bm = 128; bn = 128; }
+  else if (!AKM && p.N <= 64 && (long)ceil_div(p.M, 128) >= 256) { bm = 128; bn = 64; }
   else { bm = 64; bn = 64; }
   if (AKM && p.split_k <= 0) {
     // reduction over rows: split so that the launch has >= ~3 blocks per CU
     const long blocks = (long)ceil_div(p.M, bm) * ceil_div(p.N, bn) * p.taps;
     long want = (768 + blocks - 1) / blocks;
-    const long max_split = (p.K + 255) / 256;    // >= 256 reduction rows per block
+    const long max_split = (p.K + wg_chunk() - 1) / wg_chunk();    // >= wg_chunk reduction rows per block
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
     p.split_k = (int)want;
   }
-  if (tuned_bk() == 32) {
-    if (bm == 128 && bn == 128) return launch_cfg<128, 128, 32, AKM, BKN>(p, aligned, stream);
-    if (bm == 128 && bn == 64) return launch_cfg<128, 64, 32, AKM, BKN>(p, aligned, stream);
-    return launch_cfg<64, 64, 32, AKM, BKN>(p, aligned, stream);
+  if (bm == 64) {
+    if (small_bk() == 32) return launch_cfg<64, 64, 32, AKM, BKN>(p, aligned, stream);
+    return launch_cfg<64, 64, 16, AKM, BKN>(p, aligned, stream);
   }
   if (bm == 128 && bn == 128) return launch_cfg<128, 128, 16, AKM, BKN>(p, aligned, stream);
-  if (bm == 128 && bn == 64) return launch_cfg<128, 64, 16, AKM, BKN>(p, aligned, stream);
-  return launch_cfg<64, 64, 16, AKM, BKN>(p, aligned, stream);
+  return launch_cfg<128, 64, 16, AKM, BKN>(p, aligned, stream);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -362,6 +461,10 @@ int ocean_launch_gemm(const GemmP& p, hipStream_t stream) {
   if (p.a_kmajor) aligned = aligned && p.M % 4 == 0 && p.N % 4 == 0;
   else if (p.b_kn) aligned = aligned && p.K % 4 == 0 && p.N % 4 == 0;
   else aligned = aligned && p.K % 4 == 0;
+  // the vector path addresses both operands with 32-bit byte offsets
+  const double a_floats = p.a_kmajor ? (double)p.K * p.lda : (double)p.M * p.lda;
+  const double b_floats = (p.b_kn ? (double)p.K * p.ldb : (double)p.N * p.ldb) + (double)(p.taps - 1) * (double)p.tap_stride_b;
+  if (a_floats >= 5.0e8 || b_floats >= 5.0e8) aligned = false;
   if (p.a_kmajor) return launch_mode<true, true>(p, aligned, stream);
   if (p.b_kn) return launch_mode<false, true>(p, aligned, stream);
   return launch_mode<false, false>(p, aligned, stream);

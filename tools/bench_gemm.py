@@ -53,3 +53,20 @@ for name, t, fl in rows:
     print(f"{name:22s} {t:8.3f} ms  {fl / t / 1e9:7.1f} TFLOP/s")
     tot_t += t; tot_f += fl
 print(f"{'TOTAL':22s} {tot_t:8.3f} ms  {tot_f / tot_t / 1e9:7.1f} TFLOP/s  (env OCEAN_GEMM_BK={os.environ.get('OCEAN_GEMM_BK', '')})")
+
+# the small linear layers of the attention / fusion / head stages: rows = batch (or 3 x batch)
+rows = []
+for Mr, K, N in ((B, 768, 128), (B, 128, 128), (B, 384, 128), (3 * B, 128, 384), (3 * B, 128, 64), (B, 128, 64), (B, 256, 128), (B, 64, 256)):
+    x = torch.randn(Mr, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") * 0.05
+    y = torch.empty(Mr, N, device="cuda")
+    dw = torch.zeros(N, K, device="cuda")
+    fl = 2.0 * Mr * K * N
+    rows.append((f"lin fwd  {Mr}x{K}->{N}", timeit(lambda: _hip.gemm(x, w, y, Mr, N, K), 20), fl))
+    rows.append((f"lin dgrad {Mr}x{K}->{N}", timeit(lambda: _hip.gemm(y, w, x, Mr, K, N, b_kn=True), 20), fl))
+    rows.append((f"lin wgrad {Mr}x{K}->{N}", timeit(lambda: _hip.gemm(y, x, dw, N, K, Mr, a_kmajor=True, b_kn=True), 20), fl))
+tot_t = tot_f = 0.0
+for name, t, fl in rows:
+    print(f"{name:22s} {t:8.3f} ms  {fl / t / 1e9:7.1f} TFLOP/s")
+    tot_t += t; tot_f += fl
+print(f"{'TOTAL':22s} {tot_t:8.3f} ms  {tot_f / tot_t / 1e9:7.1f} TFLOP/s  (env OCEAN_GEMM_BK={os.environ.get('OCEAN_GEMM_BK', '')})")
