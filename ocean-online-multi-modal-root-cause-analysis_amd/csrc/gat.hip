@@ -327,6 +327,158 @@ __global__ __launch_bounds__(256) void gat_bwd_source_fast_kernel(GatK g, int hl
   store_row<CPL>(dZ + node * g.HC + c0, dz);
 }
 
+// ---- node-streaming passes of the fast path ----------------------------------------------------------------
+// A launch of kStreamBlocks blocks walks all (replica, node) rows, one row per wave per trip, lanes on channels
+// as above.  Per-channel sums over rows (bias and attention-vector gradients) stay in registers for the whole
+// walk and leave the block as one atomic per channel into one of kSumSlots copies (same-address atomics
+// serialise at the memory side), which fold_slots_kernel adds into the gradient.
+constexpr int kStreamBlocks = 2048;
+constexpr int kSumSlots = 32;
+
+template <int CPL>
+__device__ __forceinline__ void block_channel_sums(const float (&v)[CPL], float* slots, int width, int c0, bool active, float* red) {
+  // red: [kWavesPerBlock][64*CPL]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) red[(wave * 64 + lane) * CPL + k] = v[k];
+  __syncthreads();
+  if (wave == 0 && active) {
+    float* dst = slots + (size_t)(blockIdx.x % kSumSlots) * width;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < kWavesPerBlock; ++w) t += red[(w * 64 + lane) * CPL + k];
+      unsafeAtomicAdd(dst + c0 + k, t);
+    }
+  }
+  __syncthreads();
+}
+
+__global__ void fold_slots_kernel(const float* __restrict__ slots, float* __restrict__ dst, int n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float t = 0.f;
+  for (int q = 0; q < kSumSlots; ++q) t += slots[(size_t)q * n + c];
+  dst[c] += t;
+}
+
+// a_s / a_d of every row (same result as gat_scores_kernel)
+template <int CPL>
+__global__ __launch_bounds__(256) void gat_scores_fast_kernel(GatK g, int hlog, const float* __restrict__ Z,
+                                                              const float* __restrict__ att_src, const float* __restrict__ att_dst,
+                                                              float* __restrict__ a_s, float* __restrict__ a_d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int LPH = 64 >> hlog, hk = lane >> (6 - hlog), c0 = lane * CPL;
+  float as_[CPL], ad_[CPL];
+  load_row<CPL>(att_src + c0, as_);
+  load_row<CPL>(att_dst + c0, ad_);
+  const long rows = (long)g.R * g.N, stride = (long)gridDim.x * kWavesPerBlock;
+  for (long node = (long)blockIdx.x * kWavesPerBlock + wave; node < rows; node += 2 * stride) {
+    const long n2 = node + stride;
+    const bool two = n2 < rows;
+    float z0[CPL], z1[CPL];
+    load_row<CPL>(Z + node * g.HC + c0, z0);
+    load_row<CPL>(Z + (two ? n2 : node) * g.HC + c0, z1);
+    float s0 = 0.f, d0 = 0.f, s1 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      s0 = fmaf(z0[k], as_[k], s0); d0 = fmaf(z0[k], ad_[k], d0);
+      s1 = fmaf(z1[k], as_[k], s1); d1 = fmaf(z1[k], ad_[k], d1);
+    }
+    for (int o = LPH >> 1; o > 0; o >>= 1) {
+      s0 += __shfl_xor(s0, o); d0 += __shfl_xor(d0, o); s1 += __shfl_xor(s1, o); d1 += __shfl_xor(d1, o);
+    }
+    if ((lane & (LPH - 1)) == 0) {
+      a_s[node * g.H + hk] = s0; a_d[node * g.H + hk] = d0;
+      if (two) { a_s[n2 * g.H + hk] = s1; a_d[n2 * g.H + hk] = d1; }
+    }
+  }
+}
+
+// dAgg, Dn and the bias-gradient partial sums in one pass (gat_bwd_epilogue_kernel + gat_bwd_dot_kernel + colsum)
+template <int CPL>
+__global__ __launch_bounds__(256) void gat_bwd_prep_fast_kernel(GatK g, int hlog, const float* __restrict__ dy, int dy_bcast_N,
+                                                                float dy_scale, const float* __restrict__ agg,
+                                                                const float* __restrict__ bias, float* __restrict__ dagg,
+                                                                float* __restrict__ Dn, float* __restrict__ bias_slots,
+                                                                int concat, DropoutP fd) {
+  __shared__ float red[kWavesPerBlock * 64 * CPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = g.H, C = g.C, LPH = 64 >> hlog, hk = lane >> (6 - hlog), c0 = lane * CPL;
+  const int od = concat ? g.HC : C;
+  const int oc0 = concat ? c0 : c0 - hk * C;          // this lane's first output channel
+  const float invH = 1.0f / (float)H;
+  float bs[CPL], gb[CPL];
+  load_row<CPL>(bias + oc0, bs);
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) gb[k] = 0.f;
+  const long rows = (long)g.R * g.N, stride = (long)gridDim.x * kWavesPerBlock;
+  for (long node = (long)blockIdx.x * kWavesPerBlock + wave; node < rows; node += stride) {
+    float a[CPL], gr[CPL], v[CPL], da[CPL];
+    load_row<CPL>(agg + node * g.HC + c0, a);
+    const long drow = dy_bcast_N > 0 ? node / dy_bcast_N : node;
+    load_row<CPL>(dy + drow * od + oc0, gr);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) v[k] = a[k];
+    if (!concat) {
+      for (int o = LPH; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) v[k] += __shfl_xor(v[k], o);
+      }
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) v[k] *= invH;
+    }
+    float dn = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      float gq = dy_bcast_N > 0 ? gr[k] * dy_scale : gr[k];
+      if (!(v[k] + bs[k] > 0.f)) gq = 0.f;
+      if (fd.p > 0.f) gq *= dropout_keep(fd, (uint64_t)(node * od + oc0 + k));
+      if (concat || hk == 0) gb[k] += gq;
+      da[k] = concat ? gq : gq * invH;
+      dn = fmaf(da[k], a[k], dn);
+    }
+    store_row<CPL>(dagg + node * g.HC + c0, da);
+    for (int o = LPH >> 1; o > 0; o >>= 1) dn += __shfl_xor(dn, o);
+    if ((lane & (LPH - 1)) == 0) Dn[node * H + hk] = dn;
+  }
+  block_channel_sums<CPL>(gb, bias_slots, od, oc0, concat || hk == 0, red);
+}
+
+// dZ += da_s*att_src + da_d*att_dst, and the attention-vector gradient partial sums
+// (gat_bwd_att_apply_kernel + gat_bwd_att_param_kernel)
+template <int CPL>
+__global__ __launch_bounds__(256) void gat_bwd_att_fast_kernel(GatK g, int hlog, const float* __restrict__ Z, float* __restrict__ dZ,
+                                                               const float* __restrict__ da_s, const float* __restrict__ da_d,
+                                                               const float* __restrict__ att_src, const float* __restrict__ att_dst,
+                                                               float* __restrict__ src_slots, float* __restrict__ dst_slots) {
+  __shared__ float red[kWavesPerBlock * 64 * CPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hk = lane >> (6 - hlog), c0 = lane * CPL;
+  float as_[CPL], ad_[CPL], gs[CPL], gd[CPL];
+  load_row<CPL>(att_src + c0, as_);
+  load_row<CPL>(att_dst + c0, ad_);
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) { gs[k] = 0.f; gd[k] = 0.f; }
+  const long rows = (long)g.R * g.N, stride = (long)gridDim.x * kWavesPerBlock;
+  for (long node = (long)blockIdx.x * kWavesPerBlock + wave; node < rows; node += stride) {
+    float z[CPL], dz[CPL];
+    load_row<CPL>(Z + node * g.HC + c0, z);
+    load_row<CPL>(dZ + node * g.HC + c0, dz);
+    const float s = da_s[node * g.H + hk], d = da_d[node * g.H + hk];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      dz[k] += s * as_[k] + d * ad_[k];
+      gs[k] = fmaf(s, z[k], gs[k]);
+      gd[k] = fmaf(d, z[k], gd[k]);
+    }
+    store_row<CPL>(dZ + node * g.HC + c0, dz);
+  }
+  block_channel_sums<CPL>(gs, src_slots, g.HC, c0, true, red);
+  block_channel_sums<CPL>(gd, dst_slots, g.HC, c0, true, red);
+}
+
 // y = dropout(relu(headmix(agg) + bias)) (+ xin), headmix = identity (concat) or mean over heads
 __global__ void gat_epilogue_kernel(const float* __restrict__ agg, const float* __restrict__ bias, const float* __restrict__ xin,
                                     float* __restrict__ y, long rows, int H, int C, int concat, DropoutP fd) {
@@ -489,12 +641,20 @@ __global__ void bcast_pool_grad_kernel(const float* __restrict__ src, float* __r
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     dst[i] = src[(i / od / N) * od + (i % od)] * scale;
 }
+// dst[i] += sum over the replicas of chunk blockIdx.y of src[r*per + i]   (dst zeroed by the caller)
+constexpr int kReplicaChunk = 32;
 __global__ void sum_replicas_kernel(const float* __restrict__ src, float* __restrict__ dst, long per, int R) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += src[(long)r * per + i];
-    dst[i] = s;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= per) return;
+  const int r0 = blockIdx.y * kReplicaChunk, r1 = min(R, r0 + kReplicaChunk);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = r0;
+  for (; r + 3 < r1; r += 4) {
+    s0 += src[(long)r * per + i]; s1 += src[(long)(r + 1) * per + i];
+    s2 += src[(long)(r + 2) * per + i]; s3 += src[(long)(r + 3) * per + i];
   }
+  for (; r < r1; ++r) s0 += src[(long)r * per + i];
+  unsafeAtomicAdd(dst + i, (s0 + s1) + (s2 + s3));
 }
 // [G, n, C] -> [G, C] mean over the middle axis
 __global__ void mean_mid_kernel(const float* __restrict__ a, float* __restrict__ out, int n, int C) {
@@ -521,7 +681,7 @@ struct GnnPlan {
   long rows;                       // R*N
   int in_dim[8], out_dim[8], concat[8], residual[8];
   size_t x0, xb, Z[8], as_[8], ad[8], smax[8], sden[8], agg[8], y[8], pooled, fwd_total;
-  size_t dY, dZ, dagg, Dn, das, dad, dpool, dx0, bwd_total;
+  size_t dY, dZ, dagg, Dn, das, dad, dpool, dx0, slots, bwd_total;
 };
 
 inline size_t al4(size_t x) { return (x + 3) & ~size_t(3); }
@@ -560,6 +720,7 @@ int make_plan(const ocean_gnn_shape* s, GnnPlan* p) {
   p->Dn = take(rows * s->H); p->das = take(rows * s->H); p->dad = take(rows * s->H);
   p->dpool = take((size_t)p->P * p->out_dim[s->layers - 1]);
   p->dx0 = take((size_t)s->N * s->D);
+  p->slots = take((size_t)3 * kSumSlots * s->D);   // bias, att_src, att_dst partial sums
   p->bwd_total = o;
   return OCEAN_OK;
 }
@@ -626,6 +787,18 @@ inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
     OCEAN_LAUNCH_CHECK();                                                                                 \
   } while (0)
 
+#define GAT_STREAM_FAST(KERNEL, ...)                                                                     \
+  do {                                                                                                    \
+    const int cpl__ = cpl_of(pl), hlog__ = ilog2(pl.H);                                                   \
+    const long nb__ = ceil_div(pl.rows, kWavesPerBlock);                                                  \
+    const dim3 grid__((unsigned)(nb__ < kStreamBlocks ? nb__ : kStreamBlocks)), block__(256);             \
+    if (cpl__ == 1) hipLaunchKernelGGL((KERNEL<1>), grid__, block__, 0, st, g, hlog__, __VA_ARGS__);      \
+    else if (cpl__ == 2) hipLaunchKernelGGL((KERNEL<2>), grid__, block__, 0, st, g, hlog__, __VA_ARGS__); \
+    else if (cpl__ == 4) hipLaunchKernelGGL((KERNEL<4>), grid__, block__, 0, st, g, hlog__, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<8>), grid__, block__, 0, st, g, hlog__, __VA_ARGS__);                 \
+    OCEAN_LAUNCH_CHECK();                                                                                 \
+  } while (0)
+
 // parameter table: in_w, in_b, then per layer (lin_w, att_src, att_dst, bias), then out_w, out_b
 inline int pg_layer(int l, int k) { return 2 + 4 * l + k; }
 inline int pg_out(int layers, int k) { return 2 + 4 * layers + k; }
@@ -662,7 +835,10 @@ int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features, const in
   for (int l = 0; l < pl.layers; ++l) {
     const GatK g = make_k(s, pl, graph, l);
     OCEAN_TRY(linear_fwd(xin, D, params[pg_layer(l, 0)], nullptr, ws + pl.Z[l], D, (int)rows, D, D, 0, st));
-    GAT_DISPATCH(gat_scores_kernel, g, ws + pl.Z[l], params[pg_layer(l, 1)], params[pg_layer(l, 2)], ws + pl.as_[l], ws + pl.ad[l]);
+    if (fast_edges(pl))
+      GAT_STREAM_FAST(gat_scores_fast_kernel, ws + pl.Z[l], params[pg_layer(l, 1)], params[pg_layer(l, 2)], ws + pl.as_[l], ws + pl.ad[l]);
+    else
+      GAT_DISPATCH(gat_scores_kernel, g, ws + pl.Z[l], params[pg_layer(l, 1)], params[pg_layer(l, 2)], ws + pl.as_[l], ws + pl.ad[l]);
     if (fast_edges(pl)) {
       GAT_DISPATCH_FAST(gat_aggregate_fast_kernel, ws + pl.Z[l], ws + pl.as_[l], ws + pl.ad[l], ws + pl.agg[l], ws + pl.smax[l], ws + pl.sden[l]);
     } else {
@@ -705,14 +881,27 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
     const float* xin = l == 0 ? (s->R > 1 ? wf + pl.xb : wf + pl.x0) : wf + pl.y[l - 1];
     const bool last = (l == Lr - 1);
     const int od = pl.out_dim[l];
-    hipLaunchKernelGGL(gat_bwd_epilogue_kernel, dim3(egrid(rows * od)), dim3(256), 0, st, last ? wb + pl.dpool : wb + pl.dY,
-                       last ? pl.pool_n : 0, last ? 1.0f / (float)pl.pool_n : 1.0f, wf + pl.agg[l], params[pg_layer(l, 3)], wb + pl.dagg, rows,
-                       H, C, pl.concat[l], feat_drop(s, l));
-    OCEAN_LAUNCH_CHECK();
-    // bias gradient: column sums of g; for head-averaged output the H slices of dAgg each hold g/H
-    if (pl.concat[l]) OCEAN_TRY(colsum_add(wb + pl.dagg, D, (int)rows, D, grads[pg_layer(l, 3)], st));
-    else for (int h = 0; h < H; ++h) OCEAN_TRY(colsum_add(wb + pl.dagg + h * C, D, (int)rows, C, grads[pg_layer(l, 3)], st));
-    GAT_DISPATCH(gat_bwd_dot_kernel, g, wb + pl.dagg, wf + pl.agg[l], wb + pl.Dn);
+    const bool fast = fast_edges(pl);
+    float* slot_b = wb + pl.slots;
+    float* slot_s = slot_b + (size_t)kSumSlots * D;
+    float* slot_d = slot_s + (size_t)kSumSlots * D;
+    if (fast) {
+      OCEAN_TRY(zero_f32(slot_b, (size_t)3 * kSumSlots * D, st));
+      GAT_STREAM_FAST(gat_bwd_prep_fast_kernel, last ? wb + pl.dpool : wb + pl.dY, last ? pl.pool_n : 0,
+                      last ? 1.0f / (float)pl.pool_n : 1.0f, wf + pl.agg[l], params[pg_layer(l, 3)], wb + pl.dagg, wb + pl.Dn,
+                      slot_b, pl.concat[l], feat_drop(s, l));
+      hipLaunchKernelGGL(fold_slots_kernel, dim3(ceil_div(od, 64)), dim3(64), 0, st, slot_b, grads[pg_layer(l, 3)], od);
+      OCEAN_LAUNCH_CHECK();
+    } else {
+      hipLaunchKernelGGL(gat_bwd_epilogue_kernel, dim3(egrid(rows * od)), dim3(256), 0, st, last ? wb + pl.dpool : wb + pl.dY,
+                         last ? pl.pool_n : 0, last ? 1.0f / (float)pl.pool_n : 1.0f, wf + pl.agg[l], params[pg_layer(l, 3)], wb + pl.dagg, rows,
+                         H, C, pl.concat[l], feat_drop(s, l));
+      OCEAN_LAUNCH_CHECK();
+      // bias gradient: column sums of g; for head-averaged output the H slices of dAgg each hold g/H
+      if (pl.concat[l]) OCEAN_TRY(colsum_add(wb + pl.dagg, D, (int)rows, D, grads[pg_layer(l, 3)], st));
+      else for (int h = 0; h < H; ++h) OCEAN_TRY(colsum_add(wb + pl.dagg + h * C, D, (int)rows, C, grads[pg_layer(l, 3)], st));
+      GAT_DISPATCH(gat_bwd_dot_kernel, g, wb + pl.dagg, wf + pl.agg[l], wb + pl.Dn);
+    }
     OCEAN_TRY(zero_f32(wb + pl.dad, rows * H, st));
     if (fast_edges(pl))
       GAT_DISPATCH_FAST(gat_bwd_source_fast_kernel, wf + pl.Z[l], wf + pl.as_[l], wf + pl.ad[l], wf + pl.smax[l], wf + pl.sden[l],
@@ -720,12 +909,21 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
     else
       GAT_DISPATCH(gat_bwd_source_kernel, g, wf + pl.Z[l], wf + pl.as_[l], wf + pl.ad[l], wf + pl.smax[l], wf + pl.sden[l],
                    wb + pl.dagg, wb + pl.Dn, wb + pl.dZ, wb + pl.das, wb + pl.dad);
-    hipLaunchKernelGGL(gat_bwd_att_param_kernel, dim3(ceil_div(D, 64), ceil_div(rows, kAttRows)), dim3(64), 0, st, wf + pl.Z[l],
-                       wb + pl.das, wb + pl.dad, grads[pg_layer(l, 1)], grads[pg_layer(l, 2)], rows, H, C);
-    OCEAN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gat_bwd_att_apply_kernel, dim3(egrid(rows * D)), dim3(256), 0, st, wb + pl.dZ, wb + pl.das, wb + pl.dad,
-                       params[pg_layer(l, 1)], params[pg_layer(l, 2)], rows, H, C);
-    OCEAN_LAUNCH_CHECK();
+    if (fast) {
+      GAT_STREAM_FAST(gat_bwd_att_fast_kernel, wf + pl.Z[l], wb + pl.dZ, wb + pl.das, wb + pl.dad, params[pg_layer(l, 1)],
+                      params[pg_layer(l, 2)], slot_s, slot_d);
+      hipLaunchKernelGGL(fold_slots_kernel, dim3(ceil_div(D, 64)), dim3(64), 0, st, slot_s, grads[pg_layer(l, 1)], D);
+      OCEAN_LAUNCH_CHECK();
+      hipLaunchKernelGGL(fold_slots_kernel, dim3(ceil_div(D, 64)), dim3(64), 0, st, slot_d, grads[pg_layer(l, 2)], D);
+      OCEAN_LAUNCH_CHECK();
+    } else {
+      hipLaunchKernelGGL(gat_bwd_att_param_kernel, dim3(ceil_div(D, 64), ceil_div(rows, kAttRows)), dim3(64), 0, st, wf + pl.Z[l],
+                         wb + pl.das, wb + pl.dad, grads[pg_layer(l, 1)], grads[pg_layer(l, 2)], rows, H, C);
+      OCEAN_LAUNCH_CHECK();
+      hipLaunchKernelGGL(gat_bwd_att_apply_kernel, dim3(egrid(rows * D)), dim3(256), 0, st, wb + pl.dZ, wb + pl.das, wb + pl.dad,
+                         params[pg_layer(l, 1)], params[pg_layer(l, 2)], rows, H, C);
+      OCEAN_LAUNCH_CHECK();
+    }
     OCEAN_TRY(linear_bwd_weight(wb + pl.dZ, D, xin, D, grads[pg_layer(l, 0)], (int)rows, D, D, st));
     // d(xin) = dZ . W (+ dY through the residual); written over dY for the next (earlier) layer
     if (pl.residual[l] && !last) {
@@ -743,7 +941,9 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
   // input projection: x0 = relu(W nf + b), shared by all replicas
   float* dx0 = wb + pl.dx0;
   if (s->R > 1) {
-    hipLaunchKernelGGL(sum_replicas_kernel, dim3(egrid((long)s->N * D)), dim3(256), 0, st, wb + pl.dY, dx0, (long)s->N * D, s->R);
+    OCEAN_TRY(zero_f32(dx0, (size_t)s->N * D, st));
+    hipLaunchKernelGGL(sum_replicas_kernel, dim3(ceil_div((long)s->N * D, 256), ceil_div(s->R, kReplicaChunk)), dim3(256), 0, st,
+                       wb + pl.dY, dx0, (long)s->N * D, s->R);
     OCEAN_LAUNCH_CHECK();
   } else {
     OCEAN_TRY(copy2d(dx0, D, wb + pl.dY, D, s->N, D, 0, st));
