@@ -366,20 +366,41 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * khalf;
+      // residual values are fetched four rows at a time with loads that do not depend on each other, so that
+      // they are in flight together instead of costing one memory round trip per element
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row_base + (r & 3) + 8 * (r >> 2);
-        if (row < p.M && col_ok) {
-          float v = acc[i][j][r] + bias;
-          if (atomic_out) {
-            unsafeAtomicAdd(Cz + (long)row * p.ldc + col, v);
-          } else {
-            if (p.R != nullptr) {
-              if (p.r_bcast_T > 0) v += p.r_scale * p.R[(long)(row / p.r_bcast_T) * p.ldr + col];
-              else v += p.R[(long)row * p.ldr + col];
+      for (int rq = 0; rq < 4; ++rq) {
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!atomic_out && p.R != nullptr) {
+          if (p.r_bcast_T > 0) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const int row = row_base + r4 + 8 * rq;
+              const bool ok = row < p.M && col_ok;
+              rv[r4] = p.r_scale * p.R[ok ? (long)(row / p.r_bcast_T) * p.ldr + col : 0];
             }
-            if (p.relu) v = fmaxf(v, 0.f);
-            Cz[(long)row * p.ldc + col] = v;
+          } else {
+            const float* rp = p.R + (long)(row_base + 8 * rq) * p.ldr + col;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const bool ok = row_base + 8 * rq + r4 < p.M && col_ok;
+              rv[r4] = ok ? rp[(long)r4 * p.ldr] : 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int r = rq * 4 + r4;
+          const int row = row_base + r4 + 8 * rq;
+          if (row < p.M && col_ok) {
+            float v = acc[i][j][r] + bias;
+            if (atomic_out) {
+              unsafeAtomicAdd(Cz + (long)row * p.ldc + col, v);
+            } else {
+              v += rv[r4];
+              if (p.relu) v = fmaxf(v, 0.f);
+              Cz[(long)row * p.ldc + col] = v;
+            }
           }
         }
       }
