@@ -45,6 +45,22 @@ def synth_inputs(B, T, N, S, rank, device):
     return metrics.to(device), logs.to(device), nf, adj, labels.to(device)
 
 
+def recorded_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` (fetch + write), from the committed rocprofv3 --pmc passes over this
+    same command (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE
+    doubled as gfx950 requires).  None when no recording matches."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    key = kernel.replace(" ", "")
+    n = tot = 0.0
+    for r in json.load(open(path)):
+        if r["kernel"].replace(" ", "") == key:
+            n += r["launches"]
+            tot += r["launches"] * (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"])
+    return tot / n if n else None
+
+
 def cpu_baseline(model, nf, adj, T, S, budget_s=25.0):
     """The CPU oracle's update step (PyTorch CPU eager, fp32) on a bounded batch, timed with the recipe of
     the reference's profiler (3 warm-up + timed iterations, perf_counter)."""
@@ -156,7 +172,9 @@ def main():
                                    "reference default hyper-parameters (dropout 0.1: every graph replica computed)",
                        "global_batch": world * B, "seq_len": T, "services": N, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": dom["kernel"],
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": recorded_traffic(dom["kernel"]),
+                         "traffic_unit": "bytes/launch (HBM-side fetch+write, separate rocprofv3 --pmc passes)",
+                         "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "kernel": dom["kernel"],
                          "launches_per_step": dom["launches"] / args.steps,
                          "avg_launch_ms": dom["total_ms"] / dom["launches"],
                          "all_gemm_ms_per_step": gemm_ms},

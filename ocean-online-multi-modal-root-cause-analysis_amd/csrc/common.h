@@ -86,6 +86,13 @@ struct GemmP {
 
 int ocean_launch_gemm(const GemmP& p, hipStream_t stream);
 
+// Up to kGemmBatchMax independent problems of the same operand storage mode (a_kmajor / b_kn) and tap count in ONE
+// launch (blockIdx.y selects the problem): the independent modality branches of the attention and fusion
+// stages are each too small to fill the chip on their own.
+constexpr int kGemmBatchMax = 3;
+struct GemmBatch { GemmP g[kGemmBatchMax]; int n; };
+int ocean_launch_gemm_batch(const GemmP* ps, int n, hipStream_t stream);
+
 // optional kernel timing (prof.hip); token is null while profiling is off
 bool ocean_prof_on();
 void ocean_prof_begin(const char* name, double flops, double bytes, hipStream_t s, void** token);

@@ -130,7 +130,7 @@ int make_plan(const ocean_fusion_shape* s, FusPlan* p) {
   p->fwd_total = o;
   o = 0;
   p->e1 = take(B * E); p->e2 = take(B * E); p->dOm = take(B * E); p->dQKV = take(9 * B * E); p->dX = take(3 * B * E);
-  p->dY2 = take(B * Pd); p->dY1 = take(B * E); p->dR = take(B * E);
+  p->dY2 = take(3 * B * Pd); p->dY1 = take(3 * B * E); p->dR = take(3 * B * E);   // one slice per modality branch
   p->bwd_total = o;
   return OCEAN_OK;
 }
@@ -170,19 +170,22 @@ int ocean_fusion_fwd(const ocean_fusion_shape* s, const float* t, const float* s
   const float* xin[3] = {t, sp, lg};
   const int xd[3] = {s->td, s->sd, s->ld};
   const DropoutP none = {0.f, 0};
-  for (int m = 0; m < 3; ++m) {
-    float* Rm = ws + pl.R + m * BE;
-    OCEAN_TRY(linear_fwd(xin[m], xd[m], P_[4 * m], P_[4 * m + 1], Rm, E, B, E, xd[m], 1, st));
-    OCEAN_TRY(layernorm_fwd(Rm, E, P_[4 * m + 2], P_[4 * m + 3], X + m * E, 3 * E, ws + pl.lnsp + (size_t)m * 2 * B, B, E, s->eps, site(s, m), st));
-  }
+  // the three modality branches run as one launch per layer
+  LinFwd l[3];
+  for (int m = 0; m < 3; ++m) l[m] = LinFwd{xin[m], xd[m], P_[4 * m], P_[4 * m + 1], ws + pl.R + m * BE, E, B, E, xd[m]};
+  OCEAN_TRY(linear_fwd_batch(l, 3, 1, st));
+  LnFwdSet ln[3];
+  for (int m = 0; m < 3; ++m)
+    ln[m] = LnFwdSet{ws + pl.R + m * BE, P_[4 * m + 2], P_[4 * m + 3], X + m * E, ws + pl.lnsp + (size_t)m * 2 * B};
+  OCEAN_TRY(layernorm_fwd_batch(ln, 3, E, 3 * E, B, E, s->eps, site(s, 0), st));
   if (s->contrastive) {
-    for (int m = 0; m < 3; ++m) {
-      float* Y1 = ws + pl.Y1 + m * BE; float* Y2 = ws + pl.Y2 + (size_t)m * B * Pd;
-      OCEAN_TRY(linear_fwd(X + m * E, 3 * E, P_[22 + 4 * m], P_[23 + 4 * m], Y1, E, B, E, E, 1, st));
-      OCEAN_TRY(dropout_inplace(Y1, E, B, E, 1, site(s, 5 + m), st));
-      OCEAN_TRY(linear_fwd(Y1, E, P_[24 + 4 * m], P_[25 + 4 * m], Y2, Pd, B, Pd, E, 0, st));
-      OCEAN_TRY(l2norm_fwd(Y2, Pd, Zp + (size_t)m * B * Pd, Pd, ws + pl.nrm + (size_t)m * B, B, Pd, 1e-12f, st));
-    }
+    for (int m = 0; m < 3; ++m) l[m] = LinFwd{X + m * E, 3 * E, P_[22 + 4 * m], P_[23 + 4 * m], ws + pl.Y1 + m * BE, E, B, E, E};
+    OCEAN_TRY(linear_fwd_batch(l, 3, 1, st));
+    OCEAN_TRY(dropout_inplace(ws + pl.Y1, E, 3 * B, E, 1, site(s, 5), st));
+    for (int m = 0; m < 3; ++m)
+      l[m] = LinFwd{ws + pl.Y1 + m * BE, E, P_[24 + 4 * m], P_[25 + 4 * m], ws + pl.Y2 + (size_t)m * B * Pd, Pd, B, Pd, E};
+    OCEAN_TRY(linear_fwd_batch(l, 3, 0, st));
+    OCEAN_TRY(l2norm_fwd(ws + pl.Y2, Pd, Zp, Pd, ws + pl.nrm, 3 * B, Pd, 1e-12f, st));
   }
   OCEAN_TRY(linear_fwd(X, E, P_[12], P_[13], ws + pl.QKV, 3 * E, 3 * B, 3 * E, E, 0, st));
   hipLaunchKernelGGL(mha3_fwd_kernel, dim3(ceil_div((long)B * s->heads, 128)), dim3(128), 0, st, ws + pl.QKV, ws + pl.probs, ws + pl.O, B, E,
@@ -226,25 +229,31 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* s
   if (dX_in) OCEAN_TRY(copy2d(dX, 3 * E, dX_in, 3 * E, B, 3 * E, 1, st));
   if (s->contrastive && dZp) {
     if (!Zp) return OCEAN_ERR_NULL;
-    for (int m = 0; m < 3; ++m) {
-      const float* Y1 = wf + pl.Y1 + m * BE;
-      OCEAN_TRY(l2norm_bwd(dZp + (size_t)m * B * Pd, Pd, Zp + (size_t)m * B * Pd, Pd, wf + pl.nrm + (size_t)m * B, wb + pl.dY2, Pd, B, Pd, 1e-12f, st));
-      OCEAN_TRY(lin_bwd(Y1, E, wb + pl.dY2, Pd, B, Pd, E, P_[24 + 4 * m], G_[24 + 4 * m], G_[25 + 4 * m], wb + pl.dY1, E, 0, st));
-      OCEAN_TRY(dropout_inplace(wb + pl.dY1, E, B, E, 1, site(s, 5 + m), st));
-      OCEAN_TRY(relu_bwd_inplace(wb + pl.dY1, E, Y1, E, B, E, st));
-      OCEAN_TRY(lin_bwd(X + m * E, 3 * E, wb + pl.dY1, E, B, E, E, P_[22 + 4 * m], G_[22 + 4 * m], G_[23 + 4 * m], dX + m * E, 3 * E, 1, st));
-    }
+    LinBwd l[3];
+    OCEAN_TRY(l2norm_bwd(dZp, Pd, Zp, Pd, wf + pl.nrm, wb + pl.dY2, Pd, 3 * B, Pd, 1e-12f, st));
+    for (int m = 0; m < 3; ++m)
+      l[m] = LinBwd{wf + pl.Y1 + m * BE, E, wb + pl.dY2 + (size_t)m * B * Pd, Pd, B, Pd, E, P_[24 + 4 * m], G_[24 + 4 * m], G_[25 + 4 * m],
+                    wb + pl.dY1 + m * BE, E};
+    OCEAN_TRY(linear_bwd_batch(l, 3, 0, st));
+    OCEAN_TRY(dropout_inplace(wb + pl.dY1, E, 3 * B, E, 1, site(s, 5), st));
+    OCEAN_TRY(relu_bwd_inplace(wb + pl.dY1, E, wf + pl.Y1, E, 3 * B, E, st));
+    for (int m = 0; m < 3; ++m)
+      l[m] = LinBwd{X + m * E, 3 * E, wb + pl.dY1 + m * BE, E, B, E, E, P_[22 + 4 * m], G_[22 + 4 * m], G_[23 + 4 * m], dX + m * E, 3 * E};
+    OCEAN_TRY(linear_bwd_batch(l, 3, 1, st));
   }
   const float* xin[3] = {t, sp, lg};
   const int xd[3] = {s->td, s->sd, s->ld};
   float* dxin[3] = {dt, dsp, dlg};
-  for (int m = 0; m < 3; ++m) {
-    const float* Rm = wf + pl.R + m * BE;
-    OCEAN_TRY(layernorm_bwd(dX + m * E, 3 * E, Rm, E, wf + pl.lnsp + (size_t)m * 2 * B, P_[4 * m + 2], wb + pl.dR, E, G_[4 * m + 2],
-                            G_[4 * m + 3], B, E, site(s, m), st));
-    OCEAN_TRY(relu_bwd_inplace(wb + pl.dR, E, Rm, E, B, E, st));
-    OCEAN_TRY(lin_bwd(xin[m], xd[m], wb + pl.dR, E, B, E, xd[m], P_[4 * m], G_[4 * m], G_[4 * m + 1], dxin[m], xd[m], 0, st));
-  }
+  LnBwdSet ln[3];
+  for (int m = 0; m < 3; ++m)
+    ln[m] = LnBwdSet{dX + m * E, wf + pl.R + m * BE, wf + pl.lnsp + (size_t)m * 2 * B, P_[4 * m + 2], wb + pl.dR + m * BE, G_[4 * m + 2],
+                     G_[4 * m + 3]};
+  OCEAN_TRY(layernorm_bwd_batch(ln, 3, 3 * E, E, E, B, E, site(s, 0), st));
+  OCEAN_TRY(relu_bwd_inplace(wb + pl.dR, E, wf + pl.R, E, 3 * B, E, st));
+  LinBwd lb[3];
+  for (int m = 0; m < 3; ++m)
+    lb[m] = LinBwd{xin[m], xd[m], wb + pl.dR + m * BE, E, B, E, xd[m], P_[4 * m], G_[4 * m], G_[4 * m + 1], dxin[m], xd[m]};
+  OCEAN_TRY(linear_bwd_batch(lb, 3, 0, st));
   return OCEAN_OK;
 }
 

@@ -37,7 +37,8 @@ __device__ __forceinline__ int xcd_swizzle(int orig, int nwg) {
 }
 
 template <int BM, int BN, int BK, bool AKM, bool BKN, bool ALIGNED>
-__global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmP p) {
+__global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmBatch batch) {
+  const GemmP& p = batch.g[blockIdx.y];
   constexpr int WN = 2;
   constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
   constexpr int PADT = 32 / BK;
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmP p) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int nwg = tiles_m * tiles_n;
+  if ((int)blockIdx.x >= nwg) return;          // the grid is sized for the largest problem of the batch
   const int bid = xcd_swizzle(blockIdx.x, nwg);
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -409,21 +411,28 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmP p) {
 }
 
 template <int BM, int BN, int BK, bool AKM, bool BKN>
-int launch_cfg(const GemmP& p, bool aligned, hipStream_t stream) {
-  const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-  dim3 grid(tiles, 1, AKM ? p.taps * (p.split_k > 0 ? p.split_k : 1) : 1);
+int launch_cfg(const GemmBatch& b, bool aligned, hipStream_t stream) {
+  int tiles = 0, zdim = 1;
+  double flops = 0.0, bytes = 0.0;
+  for (int q = 0; q < b.n; ++q) {
+    const GemmP& p = b.g[q];
+    const int t = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    if (t > tiles) tiles = t;
+    if (AKM) zdim = p.taps * (p.split_k > 0 ? p.split_k : 1);
+    flops += 2.0 * p.M * p.N * (double)p.K * p.taps;
+    bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K * p.taps + (double)p.M * p.N * (AKM ? p.taps : 1));
+  }
+  dim3 grid(tiles, b.n, zdim);
   void* tok = nullptr;
   if (ocean_prof_on()) {
     char name[96];
     snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%d,%d,%s,%s,%s>", BM, BN, BK, AKM ? "true" : "false", BKN ? "true" : "false",
              aligned ? "true" : "false");
-    const double flops = 2.0 * p.M * p.N * (double)p.K * p.taps;
-    const double bytes = 4.0 * ((double)p.M * p.K * (AKM ? 1 : 1) + (double)p.N * p.K * p.taps + (double)p.M * p.N * (AKM ? p.taps : 1));
     ocean_prof_begin(name, flops, bytes, stream, &tok);
   }
   static const int dyn_lds = [] { const char* e = getenv("OCEAN_GEMM_DYNLDS"); return e ? atoi(e) : 0; }();   // occupancy experiments
-  if (aligned) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, true>), grid, dim3(kThreads), dyn_lds, stream, p);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, false>), grid, dim3(kThreads), dyn_lds, stream, p);
+  if (aligned) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, true>), grid, dim3(kThreads), dyn_lds, stream, b);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, false>), grid, dim3(kThreads), dyn_lds, stream, b);
   ocean_prof_end(tok, stream);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
@@ -441,36 +450,47 @@ inline int wg_chunk() { static const int v = env_int("OCEAN_GEMM_WG_CHUNK", 256)
 inline long wg_big_k() { static const int v = env_int("OCEAN_GEMM_WG_BIGK", 8192); return v; }
 
 template <bool AKM, bool BKN>
-int launch_mode(GemmP p, bool aligned, hipStream_t stream) {
-  // tile choice: wide tiles only when they still fill the chip
-  const bool big_m = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128) >= 256;
+int launch_mode(GemmBatch b, bool aligned, hipStream_t stream) {
+  // tile choice from the largest problem: wide tiles only when they still fill the chip
+  int M = 0, N = 0, K = 0, taps = b.g[0].taps;
+  long tiles128 = 0;
+  for (int q = 0; q < b.n; ++q) {
+    if (b.g[q].M > M) M = b.g[q].M;
+    if (b.g[q].N > N) N = b.g[q].N;
+    if (b.g[q].K > K) K = b.g[q].K;
+    tiles128 += (long)ceil_div(b.g[q].M, 128) * ceil_div(b.g[q].N, 128);
+  }
+  const bool big_m = tiles128 >= 256;
   int bm, bn;
-  if (AKM && p.M >= 128 && p.N >= 128 && p.K >= wg_big_k()) { bm = 128; bn = 128; }   // long row reductions fill the chip through split-K
-  else if (!AKM && p.N > 64 && big_m) { bm = 128; bn = 128; }
-  else if (!AKM && p.N <= 64 && (long)ceil_div(p.M, 128) >= 256) { bm = 128; bn = 64; }
+  if (AKM && M >= 128 && N >= 128 && K >= wg_big_k()) { bm = 128; bn = 128; }   // long row reductions fill the chip through split-K
+  else if (!AKM && N > 64 && big_m) { bm = 128; bn = 128; }
+  else if (!AKM && N <= 64 && (long)ceil_div(M, 128) * b.n >= 256) { bm = 128; bn = 64; }
   else { bm = 64; bn = 64; }
-  if (AKM && p.split_k <= 0) {
-    // reduction over rows: split so that the launch has >= ~3 blocks per CU
-    const long blocks = (long)ceil_div(p.M, bm) * ceil_div(p.N, bn) * p.taps;
-    long want = (768 + blocks - 1) / blocks;
-    const long max_split = (p.K + wg_chunk() - 1) / wg_chunk();    // >= wg_chunk reduction rows per block
-    if (want > max_split) want = max_split;
-    if (want < 1) want = 1;
-    p.split_k = (int)want;
+  if (AKM) {
+    int split = b.g[0].split_k;
+    if (split <= 0) {
+      // reduction over rows: split so that the launch has >= ~3 blocks per CU
+      long blocks = 0;
+      for (int q = 0; q < b.n; ++q) blocks += (long)ceil_div(b.g[q].M, bm) * ceil_div(b.g[q].N, bn) * taps;
+      long want = (768 + blocks - 1) / blocks;
+      const long max_split = (K + wg_chunk() - 1) / wg_chunk();    // >= wg_chunk reduction rows per block
+      if (want > max_split) want = max_split;
+      if (want < 1) want = 1;
+      split = (int)want;
+    }
+    for (int q = 0; q < b.n; ++q) b.g[q].split_k = split;
   }
   if (bm == 64) {
-    if (small_bk() == 32) return launch_cfg<64, 64, 32, AKM, BKN>(p, aligned, stream);
-    return launch_cfg<64, 64, 16, AKM, BKN>(p, aligned, stream);
+    if (small_bk() == 32) return launch_cfg<64, 64, 32, AKM, BKN>(b, aligned, stream);
+    return launch_cfg<64, 64, 16, AKM, BKN>(b, aligned, stream);
   }
-  if (bm == 128 && bn == 128) return launch_cfg<128, 128, 16, AKM, BKN>(p, aligned, stream);
-  return launch_cfg<128, 64, 16, AKM, BKN>(p, aligned, stream);
+  if (bm == 128 && bn == 128) return launch_cfg<128, 128, 16, AKM, BKN>(b, aligned, stream);
+  return launch_cfg<128, 64, 16, AKM, BKN>(b, aligned, stream);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-}  // namespace
-
-int ocean_launch_gemm(const GemmP& p, hipStream_t stream) {
+int check_problem(const GemmP& p, bool* aligned_out) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.taps < 1) return OCEAN_ERR_BAD_SHAPE;
   if (!p.A || !p.B || !p.C) return OCEAN_ERR_NULL;
   if (p.a_kmajor && !p.b_kn) return OCEAN_ERR_UNSUPPORTED;
@@ -486,7 +506,29 @@ int ocean_launch_gemm(const GemmP& p, hipStream_t stream) {
   const double a_floats = p.a_kmajor ? (double)p.K * p.lda : (double)p.M * p.lda;
   const double b_floats = (p.b_kn ? (double)p.K * p.ldb : (double)p.N * p.ldb) + (double)(p.taps - 1) * (double)p.tap_stride_b;
   if (a_floats >= 5.0e8 || b_floats >= 5.0e8) aligned = false;
-  if (p.a_kmajor) return launch_mode<true, true>(p, aligned, stream);
-  if (p.b_kn) return launch_mode<false, true>(p, aligned, stream);
-  return launch_mode<false, false>(p, aligned, stream);
+  *aligned_out = aligned;
+  return OCEAN_OK;
 }
+
+}  // namespace
+
+int ocean_launch_gemm_batch(const GemmP* ps, int n, hipStream_t stream) {
+  if (!ps || n < 1 || n > kGemmBatchMax) return OCEAN_ERR_BAD_SHAPE;
+  GemmBatch b;
+  b.n = n;
+  bool aligned = true;
+  for (int q = 0; q < n; ++q) {
+    bool al = false;
+    OCEAN_TRY(check_problem(ps[q], &al));
+    aligned = aligned && al;
+    if (ps[q].a_kmajor != ps[0].a_kmajor || ps[q].b_kn != ps[0].b_kn || ps[q].taps != ps[0].taps) return OCEAN_ERR_UNSUPPORTED;
+    if (ps[q].a_kmajor && (ps[q].K != ps[0].K || ps[q].split_k != ps[0].split_k)) return OCEAN_ERR_UNSUPPORTED;
+    b.g[q] = ps[q];
+  }
+  for (int q = n; q < kGemmBatchMax; ++q) b.g[q] = ps[0];
+  if (ps[0].a_kmajor) return launch_mode<true, true>(b, aligned, stream);
+  if (ps[0].b_kn) return launch_mode<false, true>(b, aligned, stream);
+  return launch_mode<false, false>(b, aligned, stream);
+}
+
+int ocean_launch_gemm(const GemmP& p, hipStream_t stream) { return ocean_launch_gemm_batch(&p, 1, stream); }

@@ -211,15 +211,20 @@ int ocean_mfa_fwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
   const float* xin[3] = {t, sp, lg};
   const int xd[3] = {s->td, s->sd, s->ld};
   const DropoutP none = {0.f, 0};
-  for (int m = 0; m < 3; ++m) {
-    float* Pm = ws + pl.P + m * BW; float* Vm = ws + pl.V + m * BW; float* Am = ws + pl.A + m * BW;
-    OCEAN_TRY(linear_fwd(xin[m], xd[m], P_[2 * m], P_[2 * m + 1], Pm, W, B, W, xd[m], 0, st));
-    OCEAN_TRY(linear_fwd(Pm, W, P_[6 + 4 * m], P_[7 + 4 * m], Vm, W, B, W, W, 0, st));
-    OCEAN_TRY(dropout_inplace(Vm, W, B, W, W / s->heads, site(s, m), st));
-    OCEAN_TRY(linear_fwd(Vm, W, P_[8 + 4 * m], P_[9 + 4 * m], Am, W, B, W, W, 0, st));
-    OCEAN_TRY(dropout_inplace(Am, W, B, W, 1, site(s, 3 + m), st));
-    OCEAN_TRY(layernorm_fwd(Am, W, P_[18 + 2 * m], P_[19 + 2 * m], ws + pl.Nn + m * BW, W, ws + pl.lnst + (size_t)m * 2 * B, B, W, s->eps, none, st));
-  }
+  // the three modality branches run as one launch per layer; dropout sites cover all three (contiguous [3, B, W])
+  LinFwd l[3];
+  for (int m = 0; m < 3; ++m) l[m] = LinFwd{xin[m], xd[m], P_[2 * m], P_[2 * m + 1], ws + pl.P + m * BW, W, B, W, xd[m]};
+  OCEAN_TRY(linear_fwd_batch(l, 3, 0, st));
+  for (int m = 0; m < 3; ++m) l[m] = LinFwd{ws + pl.P + m * BW, W, P_[6 + 4 * m], P_[7 + 4 * m], ws + pl.V + m * BW, W, B, W, W};
+  OCEAN_TRY(linear_fwd_batch(l, 3, 0, st));
+  OCEAN_TRY(dropout_inplace(ws + pl.V, W, 3 * B, W, W / s->heads, site(s, 0), st));
+  for (int m = 0; m < 3; ++m) l[m] = LinFwd{ws + pl.V + m * BW, W, P_[8 + 4 * m], P_[9 + 4 * m], ws + pl.A + m * BW, W, B, W, W};
+  OCEAN_TRY(linear_fwd_batch(l, 3, 0, st));
+  OCEAN_TRY(dropout_inplace(ws + pl.A, W, 3 * B, W, 1, site(s, 3), st));
+  LnFwdSet ln[3];
+  for (int m = 0; m < 3; ++m)
+    ln[m] = LnFwdSet{ws + pl.A + m * BW, P_[18 + 2 * m], P_[19 + 2 * m], ws + pl.Nn + m * BW, ws + pl.lnst + (size_t)m * 2 * B};
+  OCEAN_TRY(layernorm_fwd_batch(ln, 3, W, W, B, W, s->eps, none, st));
   hipLaunchKernelGGL(cross_fwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.Nn, P_[26], ws + pl.G, ws + pl.cw, B, W);
   OCEAN_LAUNCH_CHECK();
   OCEAN_TRY(linear_fwd(ws + pl.G, W, P_[27], P_[28], ws + pl.Hd, Wh, 3 * B, Wh, W, 1, st));
@@ -267,16 +272,23 @@ int ocean_mfa_bwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
   const float* xin[3] = {t, sp, lg};
   const int xd[3] = {s->td, s->sd, s->ld};
   float* dxin[3] = {dt, dsp, dlg};
-  for (int m = 0; m < 3; ++m) {
-    float* g2 = d2 + m * BW; float* g1 = d1 + m * BW;
-    OCEAN_TRY(layernorm_bwd(g2, W, wf + pl.A + m * BW, W, wf + pl.lnst + (size_t)m * 2 * B, P_[18 + 2 * m], g2, W, G_[18 + 2 * m],
-                            G_[19 + 2 * m], B, W, none, st));
-    OCEAN_TRY(dropout_inplace(g2, W, B, W, 1, site(s, 3 + m), st));
-    OCEAN_TRY(lin_bwd(wf + pl.V + m * BW, W, g2, W, B, W, W, P_[8 + 4 * m], G_[8 + 4 * m], G_[9 + 4 * m], g1, W, 0, st));
-    OCEAN_TRY(dropout_inplace(g1, W, B, W, W / s->heads, site(s, m), st));
-    OCEAN_TRY(lin_bwd(wf + pl.P + m * BW, W, g1, W, B, W, W, P_[6 + 4 * m], G_[6 + 4 * m], G_[7 + 4 * m], g2, W, 0, st));
-    OCEAN_TRY(lin_bwd(xin[m], xd[m], g2, W, B, W, xd[m], P_[2 * m], G_[2 * m], G_[2 * m + 1], dxin[m], xd[m], 0, st));
-  }
+  LnBwdSet ln[3];
+  for (int m = 0; m < 3; ++m)
+    ln[m] = LnBwdSet{d2 + m * BW, wf + pl.A + m * BW, wf + pl.lnst + (size_t)m * 2 * B, P_[18 + 2 * m], d2 + m * BW, G_[18 + 2 * m],
+                     G_[19 + 2 * m]};
+  OCEAN_TRY(layernorm_bwd_batch(ln, 3, W, W, W, B, W, none, st));
+  OCEAN_TRY(dropout_inplace(d2, W, 3 * B, W, 1, site(s, 3), st));
+  LinBwd l[3];
+  for (int m = 0; m < 3; ++m)
+    l[m] = LinBwd{wf + pl.V + m * BW, W, d2 + m * BW, W, B, W, W, P_[8 + 4 * m], G_[8 + 4 * m], G_[9 + 4 * m], d1 + m * BW, W};
+  OCEAN_TRY(linear_bwd_batch(l, 3, 0, st));
+  OCEAN_TRY(dropout_inplace(d1, W, 3 * B, W, W / s->heads, site(s, 0), st));
+  for (int m = 0; m < 3; ++m)
+    l[m] = LinBwd{wf + pl.P + m * BW, W, d1 + m * BW, W, B, W, W, P_[6 + 4 * m], G_[6 + 4 * m], G_[7 + 4 * m], d2 + m * BW, W};
+  OCEAN_TRY(linear_bwd_batch(l, 3, 0, st));
+  for (int m = 0; m < 3; ++m)
+    l[m] = LinBwd{xin[m], xd[m], d2 + m * BW, W, B, W, xd[m], P_[2 * m], G_[2 * m], G_[2 * m + 1], dxin[m], xd[m]};
+  OCEAN_TRY(linear_bwd_batch(l, 3, 0, st));
   return OCEAN_OK;
 }
 

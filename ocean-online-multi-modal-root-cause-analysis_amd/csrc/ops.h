@@ -11,6 +11,14 @@ int linear_bwd_data(const float* dy, int lddy, const float* W, float* dx, int ld
 // dW[N,K] += dy[M,N]^T . x[M,K]                          (nn.Linear weight gradient, atomic accumulate)
 int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float* dW,
                       int M, int N, int K, hipStream_t s);
+// Batched forms: up to kGemmBatchMax independent layers (the three modality branches) per launch.
+struct LinFwd { const float* x; int ldx; const float* W; const float* b; float* y; int ldy; int M, N, K; };
+int linear_fwd_batch(const LinFwd* l, int n, int relu, hipStream_t s);
+// one layer's backward: dW += dy^T x, db += colsum(dy), dx (+)= dy W; null outputs are skipped
+struct LinBwd { const float* x; int ldx; const float* dy; int lddy; int M, N, K; const float* W; float* dW; float* db; float* dx; int lddx; };
+int linear_bwd_batch(const LinBwd* l, int n, int accumulate_dx, hipStream_t s);
+struct ColSum { const float* a; int lda; int M, N; float* out; };
+int colsum_add_batch(const ColSum* c, int n, hipStream_t s);
 // out[N] += column sums of a[M,N]                         (bias gradients)
 int colsum_add(const float* a, int lda, int M, int N, float* out, hipStream_t s);
 // dy[i] = (y[i] > 0) ? dy[i] : 0   over an [M,N] matrix with leading dims    (ReLU backward on the saved output)
@@ -28,6 +36,12 @@ int layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta
 // dx = d/dx of the above (dropout mask re-applied); dgamma/dbeta accumulated.  dx may alias dy.
 int layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* stats, const float* gamma,
                   float* dx, int lddx, float* dgamma, float* dbeta, int rows, int W, DropoutP in_drop, hipStream_t s);
+// Batched LayerNorm: set q has its own tensors and parameters, all sets share the shape and leading dimensions;
+// the dropout index of set q, row r, column c is (q*rows + r)*W + c.
+struct LnFwdSet { const float* x; const float* gamma; const float* beta; float* y; float* stats; };
+int layernorm_fwd_batch(const LnFwdSet* sets, int n, int ldx, int ldy, int rows, int W, float eps, DropoutP in_drop, hipStream_t s);
+struct LnBwdSet { const float* dy; const float* x; const float* stats; const float* gamma; float* dx; float* dgamma; float* dbeta; };
+int layernorm_bwd_batch(const LnBwdSet* sets, int n, int lddy, int ldx, int lddx, int rows, int W, DropoutP in_drop, hipStream_t s);
 // y = x / max(||x||_2, eps) per row; norms[row] saved
 int l2norm_fwd(const float* x, int ldx, float* y, int ldy, float* norms, int rows, int W, float eps, hipStream_t s);
 // dx = (dy - y * (y . dy)) / max(norm, eps); dx may alias dy

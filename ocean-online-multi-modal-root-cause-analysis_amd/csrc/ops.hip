@@ -28,14 +28,63 @@ int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float*
   return ocean_launch_gemm(p, s);
 }
 
+int linear_fwd_batch(const LinFwd* l, int n, int relu, hipStream_t s) {
+  if (n < 1 || n > kGemmBatchMax) return OCEAN_ERR_BAD_SHAPE;
+  GemmP g[kGemmBatchMax];
+  for (int q = 0; q < n; ++q) {
+    g[q] = gemm_defaults();
+    g[q].A = l[q].x; g[q].lda = l[q].ldx; g[q].B = l[q].W; g[q].ldb = l[q].K; g[q].C = l[q].y; g[q].ldc = l[q].ldy;
+    g[q].M = l[q].M; g[q].N = l[q].N; g[q].K = l[q].K; g[q].bias = l[q].b; g[q].relu = relu;
+  }
+  return ocean_launch_gemm_batch(g, n, s);
+}
+
+int linear_bwd_batch(const LinBwd* l, int n, int accumulate_dx, hipStream_t s) {
+  if (n < 1 || n > kGemmBatchMax) return OCEAN_ERR_BAD_SHAPE;
+  GemmP g[kGemmBatchMax];
+  int k = 0;
+  for (int q = 0; q < n; ++q) {
+    if (!l[q].dW) continue;
+    g[k] = gemm_defaults();
+    g[k].A = l[q].dy; g[k].lda = l[q].lddy; g[k].a_kmajor = 1; g[k].B = l[q].x; g[k].ldb = l[q].ldx; g[k].b_kn = 1;
+    g[k].C = l[q].dW; g[k].ldc = l[q].K; g[k].M = l[q].N; g[k].N = l[q].K; g[k].K = l[q].M; g[k].split_k = 0;
+    ++k;
+  }
+  if (k > 0) OCEAN_TRY(ocean_launch_gemm_batch(g, k, s));
+  ColSum c[kGemmBatchMax];
+  k = 0;
+  for (int q = 0; q < n; ++q) {
+    if (!l[q].db) continue;
+    c[k].a = l[q].dy; c[k].lda = l[q].lddy; c[k].M = l[q].M; c[k].N = l[q].N; c[k].out = l[q].db;
+    ++k;
+  }
+  if (k > 0) OCEAN_TRY(colsum_add_batch(c, k, s));
+  k = 0;
+  for (int q = 0; q < n; ++q) {
+    if (!l[q].dx) continue;
+    g[k] = gemm_defaults();
+    g[k].A = l[q].dy; g[k].lda = l[q].lddy; g[k].B = l[q].W; g[k].ldb = l[q].K; g[k].b_kn = 1; g[k].C = l[q].dx; g[k].ldc = l[q].lddx;
+    g[k].M = l[q].M; g[k].N = l[q].K; g[k].K = l[q].N;
+    if (accumulate_dx) { g[k].R = l[q].dx; g[k].ldr = l[q].lddx; }
+    ++k;
+  }
+  if (k > 0) OCEAN_TRY(ocean_launch_gemm_batch(g, k, s));
+  return OCEAN_OK;
+}
+
 namespace {
+
+struct ColSumBatch { ColSum c[kGemmBatchMax]; };
 
 // Column sums: a block is W column groups (VEC consecutive columns each, W a power of two) by 256/W row lanes
 // over `rows` rows; consecutive lanes read consecutive addresses, eight rows are in flight per thread, and each
 // block issues one atomic per column.
 template <int VEC>
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int lda, int M, int N, float* __restrict__ out,
-                                                     int wlog, int rows) {
+__global__ __launch_bounds__(256) void colsum_kernel(const ColSumBatch batch, int wlog, int rows) {
+  const ColSum& cs = batch.c[blockIdx.z];
+  const float* __restrict__ a = cs.a;
+  float* __restrict__ out = cs.out;
+  const int lda = cs.lda, M = cs.M, N = cs.N;
   __shared__ float red[256 * VEC];
   const int W = 1 << wlog, RL = 256 >> wlog;
   const int tx = threadIdx.x & (W - 1), ty = threadIdx.x >> wlog;
@@ -100,9 +149,19 @@ inline int grid_for(long n, int block = 256, int cap = 4096) {
 
 }  // namespace
 
-int colsum_add(const float* a, int lda, int M, int N, float* out, hipStream_t s) {
-  if (M <= 0 || N <= 0) return OCEAN_ERR_BAD_SHAPE;
-  const bool v4 = (N % 4 == 0) && (lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0);
+int colsum_add_batch(const ColSum* c, int n, hipStream_t s) {
+  if (n < 1 || n > kGemmBatchMax) return OCEAN_ERR_BAD_SHAPE;
+  ColSumBatch b;
+  bool v4 = true;
+  int M = 0, N = 0;
+  for (int q = 0; q < n; ++q) {
+    if (c[q].M <= 0 || c[q].N <= 0) return OCEAN_ERR_BAD_SHAPE;
+    v4 = v4 && (c[q].N % 4 == 0) && (c[q].lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(c[q].a) & 15) == 0);
+    if (c[q].M > M) M = c[q].M;
+    if (c[q].N > N) N = c[q].N;
+    b.c[q] = c[q];
+  }
+  for (int q = n; q < kGemmBatchMax; ++q) b.c[q] = c[0];
   const int vec = v4 ? 4 : 1;
   const int cg = (N + vec - 1) / vec;
   int wlog = 0;
@@ -111,11 +170,17 @@ int colsum_add(const float* a, int lda, int M, int N, float* out, hipStream_t s)
   // Same-address atomics serialise at the memory side (~tens of ns each): keep them to <= 256 per column.
   int rows = RL * 4;
   if (rows < ceil_div(M, 256)) rows = ceil_div(M, 256);
-  dim3 grid(ceil_div(cg, 1 << wlog), ceil_div(M, rows));
-  if (v4) hipLaunchKernelGGL(colsum_kernel<4>, grid, dim3(256), 0, s, a, lda, M, N, out, wlog, rows);
-  else hipLaunchKernelGGL(colsum_kernel<1>, grid, dim3(256), 0, s, a, lda, M, N, out, wlog, rows);
+  dim3 grid(ceil_div(cg, 1 << wlog), ceil_div(M, rows), n);
+  if (v4) hipLaunchKernelGGL(colsum_kernel<4>, grid, dim3(256), 0, s, b, wlog, rows);
+  else hipLaunchKernelGGL(colsum_kernel<1>, grid, dim3(256), 0, s, b, wlog, rows);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
+}
+
+int colsum_add(const float* a, int lda, int M, int N, float* out, hipStream_t s) {
+  ColSum c;
+  c.a = a; c.lda = lda; c.M = M; c.N = N; c.out = out;
+  return colsum_add_batch(&c, 1, s);
 }
 
 int relu_bwd_inplace(float* dy, int lddy, const float* y, int ldy, int M, int N, hipStream_t s) {

@@ -14,14 +14,22 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 constexpr int kWaves = 4;
+constexpr int kLnSets = 3;
+struct LnFwdBatch { LnFwdSet s[kLnSets]; };
+struct LnBwdBatch { LnBwdSet s[kLnSets]; };
 
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ y, int ldy,
-                                                     float* __restrict__ stats, int rows, int W, float eps, DropoutP dp) {
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdBatch batch, int ldx, int ldy, int rows, int W, float eps, DropoutP dp) {
+  const LnFwdSet& st = batch.s[blockIdx.y];
+  const float* __restrict__ x = st.x;
+  const float* __restrict__ gamma = st.gamma;
+  const float* __restrict__ beta = st.beta;
+  float* __restrict__ y = st.y;
+  float* __restrict__ stats = st.stats;
   const int lane = threadIdx.x & 63, row = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + (long)row * ldx;
-  auto val = [&](int c) { float v = xr[c]; if (dp.p > 0.f) v *= dropout_keep(dp, (uint64_t)row * W + c); return v; };
+  const uint64_t drow = (uint64_t)blockIdx.y * rows + row;
+  auto val = [&](int c) { float v = xr[c]; if (dp.p > 0.f) v *= dropout_keep(dp, drow * W + c); return v; };
   float s = 0.f;
   for (int c = lane; c < W; c += 64) s += val(c);
   const float mean = wave_sum(s) / (float)W;
@@ -36,10 +44,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // per-column gamma/beta partial sums stay in registers (up to 16 columns per lane).
 constexpr int kLnRowsPerBlock = 32;
 constexpr int kMaxColsPerLane = 16;
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
-                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                     float* __restrict__ dx, int lddx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int rows, int W, DropoutP dp) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdBatch batch, int lddy, int ldx, int lddx, int rows, int W, DropoutP dp) {
+  const LnBwdSet& st = batch.s[blockIdx.y];
+  const float* __restrict__ dy = st.dy;
+  const float* __restrict__ x = st.x;
+  const float* __restrict__ stats = st.stats;
+  const float* __restrict__ gamma = st.gamma;
+  float* __restrict__ dx = st.dx;
+  float* __restrict__ dgamma = st.dgamma;
+  float* __restrict__ dbeta = st.dbeta;
+  const uint64_t drow0 = (uint64_t)blockIdx.y * rows;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float pg[kMaxColsPerLane], pb[kMaxColsPerLane];
 #pragma unroll
@@ -55,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       const int c = lane + 64 * k;
       if (c < W) {
         float xv = xr[c];
-        if (dp.p > 0.f) xv *= dropout_keep(dp, (uint64_t)row * W + c);
+        if (dp.p > 0.f) xv *= dropout_keep(dp, (drow0 + row) * W + c);
         const float xh = (xv - mean) * rstd, g = gr[c];
         pg[k] += g * xh; pb[k] += g;
         const float dxh = g * gamma[c];
@@ -68,7 +82,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       const int c = lane + 64 * k;
       if (c < W) {
         float keep = 1.f, xv = xr[c];
-        if (dp.p > 0.f) { keep = dropout_keep(dp, (uint64_t)row * W + c); xv *= keep; }
+        if (dp.p > 0.f) { keep = dropout_keep(dp, (drow0 + row) * W + c); xv *= keep; }
         const float xh = (xv - mean) * rstd;
         dx[(long)row * lddx + c] = rstd * (gr[c] * gamma[c] - s1 - xh * s2) * keep;
       }
@@ -141,22 +155,37 @@ __global__ void mean_mid_kernel2(const float* __restrict__ a, float* __restrict_
 
 }  // namespace
 
+int layernorm_fwd_batch(const LnFwdSet* sets, int n, int ldx, int ldy, int rows, int W, float eps, DropoutP in_drop, hipStream_t s) {
+  if (rows <= 0 || W <= 0 || n < 1 || n > kLnSets) return OCEAN_ERR_BAD_SHAPE;
+  LnFwdBatch b;
+  for (int q = 0; q < kLnSets; ++q) b.s[q] = sets[q < n ? q : 0];
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, kWaves), n), dim3(256), 0, s, b, ldx, ldy, rows, W, eps, in_drop);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
 int layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, float* stats,
                   int rows, int W, float eps, DropoutP in_drop, hipStream_t s) {
-  if (rows <= 0 || W <= 0) return OCEAN_ERR_BAD_SHAPE;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, kWaves)), dim3(256), 0, s, x, ldx, gamma, beta, y, ldy, stats, rows, W, eps, in_drop);
+  LnFwdSet st;
+  st.x = x; st.gamma = gamma; st.beta = beta; st.y = y; st.stats = stats;
+  return layernorm_fwd_batch(&st, 1, ldx, ldy, rows, W, eps, in_drop, s);
+}
+
+int layernorm_bwd_batch(const LnBwdSet* sets, int n, int lddy, int ldx, int lddx, int rows, int W, DropoutP in_drop, hipStream_t s) {
+  if (rows <= 0 || W <= 0 || n < 1 || n > kLnSets) return OCEAN_ERR_BAD_SHAPE;
+  if (W > 64 * kMaxColsPerLane) return OCEAN_ERR_UNSUPPORTED;
+  LnBwdBatch b;
+  for (int q = 0; q < kLnSets; ++q) b.s[q] = sets[q < n ? q : 0];
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, kLnRowsPerBlock), n), dim3(256), 0, s, b, lddy, ldx, lddx, rows, W, in_drop);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }
 
 int layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const float* stats, const float* gamma,
                   float* dx, int lddx, float* dgamma, float* dbeta, int rows, int W, DropoutP in_drop, hipStream_t s) {
-  if (rows <= 0 || W <= 0) return OCEAN_ERR_BAD_SHAPE;
-  if (W > 64 * kMaxColsPerLane) return OCEAN_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, kLnRowsPerBlock)), dim3(256), 0, s, dy, lddy, x, ldx, stats, gamma, dx, lddx,
-                     dgamma, dbeta, rows, W, in_drop);
-  OCEAN_LAUNCH_CHECK();
-  return OCEAN_OK;
+  LnBwdSet st;
+  st.dy = dy; st.x = x; st.stats = stats; st.gamma = gamma; st.dx = dx; st.dgamma = dgamma; st.dbeta = dbeta;
+  return layernorm_bwd_batch(&st, 1, lddy, ldx, lddx, rows, W, in_drop, s);
 }
 
 int l2norm_fwd(const float* x, int ldx, float* y, int ldy, float* norms, int rows, int W, float eps, hipStream_t s) {
