@@ -185,3 +185,62 @@ def test_model_requires_gpu_and_library():
     m = ocean.OCEANModel(tiny_config())
     with pytest.raises(_hip.OceanHipError):
         m(torch.randn(1, 4, 5), ServiceGraph(torch.eye(3), torch.randn(3, 7)), torch.randn(1, 24))
+
+
+@pytest.mark.parametrize("neg", ["bank", "in_batch"])
+def test_dropout_backward_matches_finite_differences(golden, neg):
+    """All dropout sites active (reference defaults): under a fixed CPU seed every component draws the same mask
+    seeds, so the training-mode loss is a deterministic function of the parameters; central differences along one
+    parameter tensor at a time must agree with the analytic gradient, which requires every backward kernel to
+    regenerate its forward mask (attention, fusion, contrastive projections, head, GAT, dilated CNN)."""
+    import ocean
+    g = golden(f"model_train_tiny_{neg}")
+    cfg = tiny_config()
+    m = ocean.OCEANModel(cfg)
+    m.load_state_dict({k[3:]: T(g[k]).clone() for k in g.files if k.startswith("sd/")})
+    m = m.cuda().train()
+    m.contrastive_negatives = neg
+    sg = graph_of(g)
+    metrics, logs, labels = T(g["s0/metrics"]).cuda(), T(g["s0/logs"]).cuda(), T(g["s0/labels"]).cuda()
+    cm = m.fusion_module.contrastive_module
+    bank0, ptr0 = cm.memory_bank.clone(), cm.memory_ptr.clone()
+    running = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+
+    def f():
+        with torch.no_grad():                       # the forward mutates the bank and the BatchNorm running statistics
+            cm.memory_bank.copy_(bank0); cm.memory_ptr.copy_(ptr0)
+            for k, v in m.state_dict().items():
+                if k in running:
+                    v.copy_(running[k])
+        torch.manual_seed(1234)
+        return m.compute_loss(m(metrics, sg, logs), labels)["total_loss"].double()
+
+    for p in m.parameters():
+        p.grad = None
+    f().backward()
+    names = dict(m.named_parameters())
+    picks = ["temporal_encoder.conv_layers.0.conv.weight", "temporal_encoder.conv_layers.1.batch_norm.weight",
+             "spatial_encoder.conv_layers.0.lin.weight", "spatial_encoder.conv_layers.1.att_src",
+             "attention_module.temporal_projection.weight", "attention_module.log_self_attention.w_v.weight",
+             "attention_module.spatial_self_attention.w_o.bias", "attention_module.layer_norms.temporal.weight",
+             "attention_module.output_projection.0.weight", "fusion_module.log_processor.0.weight",
+             "fusion_module.spatial_processor.3.weight", "fusion_module.attention_fusion.in_proj_weight",
+             "fusion_module.contrastive_module.projection_heads.log.projection.0.weight",
+             "fusion_module.contrastive_module.projection_heads.temporal.projection.3.weight",
+             "fusion_module.output_projection.3.weight", "prediction_head.3.weight"]
+    picks = [k for k in picks if k in names and names[k].grad is not None]
+    assert len(picks) >= 14, picks
+    grads = {k: names[k].grad.clone() for k in picks}
+    eps = 2e-3
+    for k in picks:
+        p = names[k]
+        d = torch.randn(p.shape, generator=torch.Generator().manual_seed(5)).cuda() * p.detach().abs().mean().clamp_min(1e-3)
+        analytic = (grads[k].double() * d.double()).sum().item()
+        with torch.no_grad():
+            p.add_(d, alpha=eps)
+            fp = f().item()
+            p.add_(d, alpha=-2 * eps)
+            fm = f().item()
+            p.add_(d, alpha=eps)
+        numeric = (fp - fm) / (2 * eps)
+        assert abs(numeric - analytic) <= 6e-2 * abs(analytic) + 2e-3, (k, numeric, analytic)
