@@ -29,6 +29,8 @@ struct GatK {
   const int* rp_out; const int* dst_out; const int* eid_out; // by source; eid = position in the by-target order
   float slope;
   DropoutP att_drop;                  // attention-coefficient dropout (GATConv's own)
+  int z_shared;                       // Z, a_s, a_d hold ONE replica ([N, .]) that every replica reads (the first layer's
+                                      // input is the same for all replicas; only the dropout masks differ)
 };
 
 constexpr int kWavesPerBlock = 4;
@@ -148,6 +150,15 @@ __global__ __launch_bounds__(256) void gat_aggregate_kernel(GatK g, const float*
 // (edge slot, head) = (lane / H, lane % H), 64/H edges at a time, and parked in wave-private LDS; the row
 // gathers then run as an unrolled loop whose only memory dependency is the row address read back from LDS,
 // so four 64-lane row loads are in flight at once instead of one load chain per edge.
+// Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  Remapping the block id so that every
+// XCD walks a contiguous range of rows keeps one graph replica's rows (which its edges gather from) in one L2
+// instead of fetching them into all eight.
+__device__ __forceinline__ long xcd_contiguous_block(unsigned orig, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7, xcd = orig & 7;
+  const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return (long)(base + (orig >> 3));
+}
+
 template <int CPL>
 __device__ __forceinline__ void load_row(const float* p, float (&v)[CPL]) {
   if (CPL == 1) { v[0] = p[0]; }
@@ -184,15 +195,15 @@ __global__ __launch_bounds__(256) void gat_aggregate_fast_kernel(GatK g, int hlo
   __shared__ int jl_all[kWavesPerBlock][64];
   __shared__ float dl_all[kWavesPerBlock][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long node = (long)blockIdx.x * kWavesPerBlock + wave;
+  const long node = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
   if (node >= (long)g.R * g.N) return;
   float* wl = wl_all[wave]; int* jl = jl_all[wave]; float* dl = dl_all[wave];
   const int r = (int)(node / g.N), i = (int)(node % g.N);
-  const long rbase = (long)r * g.N;
+  const long rbase = g.z_shared ? 0 : (long)r * g.N;   // base row of this replica in Z / a_s / a_d
   const int H = g.H, EPW = 64 >> hlog;
   const int le = lane >> hlog, lh = lane & (H - 1);   // edge-role coordinates
   const int hk = lane >> (6 - hlog), c0 = lane * CPL;  // channel-role coordinates
-  const float adl = a_d[node * H + lh];
+  const float adl = a_d[(rbase + i) * H + lh];
   const int e0 = g.rp_in[i], e1 = g.rp_in[i + 1];
   const bool single = (e1 - e0) <= EPW;
   float mx = -INFINITY, s_last = -INFINITY;
@@ -261,19 +272,20 @@ __global__ __launch_bounds__(256) void gat_bwd_source_fast_kernel(GatK g, int hl
   __shared__ float hl_all[kWavesPerBlock][64];
   __shared__ int il_all[kWavesPerBlock][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long node = (long)blockIdx.x * kWavesPerBlock + wave;
+  const long node = xcd_contiguous_block(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
   if (node >= (long)g.R * g.N) return;
   float* wl = wl_all[wave]; float* hl = hl_all[wave]; int* il = il_all[wave];
   const int r = (int)(node / g.N), j = (int)(node % g.N);
   const long rbase = (long)r * g.N;
+  const long zbase = g.z_shared ? 0 : rbase;               // base row of this replica in Z / a_s / a_d
   const int H = g.H, EPW = 64 >> hlog, LPH = 64 >> hlog;   // edges per pass; lanes per head in the channel role
   const int le = lane >> hlog, lh = lane & (H - 1);
   const int hk = lane >> (6 - hlog), c0 = lane * CPL;
   float z[CPL], dz[CPL];
-  load_row<CPL>(Z + node * g.HC + c0, z);
+  load_row<CPL>(Z + (zbase + j) * g.HC + c0, z);
 #pragma unroll
   for (int k = 0; k < CPL; ++k) dz[k] = 0.f;
-  const float asl = a_s[node * H + lh];
+  const float asl = a_s[(zbase + j) * H + lh];
   float das = 0.f;
   const int e0 = g.rp_out[j], e1 = g.rp_out[j + 1];
   for (int base = e0; base < e1; base += EPW) {
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256) void gat_bwd_source_fast_kernel(GatK g, int hl
     const bool valid = e < e1;
     const int i = valid ? g.dst_out[e] : j;
     const long nh = (rbase + i) * H + lh;
-    const float raw = asl + a_d[nh];
+    const float raw = asl + a_d[(zbase + i) * H + lh];
     const float alpha = valid ? __expf(lrelu(raw, g.slope) - smax[nh]) / (sden[nh] + 1e-16f) : 0.f;
     float keep = 1.f;
     if (g.att_drop.p > 0.f && valid) keep = dropout_keep(g.att_drop, ((uint64_t)r * g.E + g.eid_out[e]) * H + lh);
@@ -373,7 +385,7 @@ __global__ __launch_bounds__(256) void gat_scores_fast_kernel(GatK g, int hlog, 
   float as_[CPL], ad_[CPL];
   load_row<CPL>(att_src + c0, as_);
   load_row<CPL>(att_dst + c0, ad_);
-  const long rows = (long)g.R * g.N, stride = (long)gridDim.x * kWavesPerBlock;
+  const long rows = g.z_shared ? (long)g.N : (long)g.R * g.N, stride = (long)gridDim.x * kWavesPerBlock;
   for (long node = (long)blockIdx.x * kWavesPerBlock + wave; node < rows; node += 2 * stride) {
     const long n2 = node + stride;
     const bool two = n2 < rows;
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(256) void gat_bwd_att_fast_kernel(GatK g, int hlog,
   const long rows = (long)g.R * g.N, stride = (long)gridDim.x * kWavesPerBlock;
   for (long node = (long)blockIdx.x * kWavesPerBlock + wave; node < rows; node += stride) {
     float z[CPL], dz[CPL];
-    load_row<CPL>(Z + node * g.HC + c0, z);
+    load_row<CPL>(Z + (g.z_shared ? node % g.N : node) * g.HC + c0, z);
     load_row<CPL>(dZ + node * g.HC + c0, dz);
     const float s = da_s[node * g.H + hk], d = da_d[node * g.H + hk];
 #pragma unroll
@@ -481,7 +493,7 @@ __global__ __launch_bounds__(256) void gat_bwd_att_fast_kernel(GatK g, int hlog,
 
 // y = dropout(relu(headmix(agg) + bias)) (+ xin), headmix = identity (concat) or mean over heads
 __global__ void gat_epilogue_kernel(const float* __restrict__ agg, const float* __restrict__ bias, const float* __restrict__ xin,
-                                    float* __restrict__ y, long rows, int H, int C, int concat, DropoutP fd) {
+                                    int xin_rows, float* __restrict__ y, long rows, int H, int C, int concat, DropoutP fd) {
   const int od = concat ? H * C : C;
   const long n = rows * od;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
@@ -496,7 +508,7 @@ __global__ void gat_epilogue_kernel(const float* __restrict__ agg, const float* 
     }
     v = fmaxf(v + bias[c], 0.f);
     if (fd.p > 0.f) v *= dropout_keep(fd, (uint64_t)idx);
-    if (xin) v += xin[idx];
+    if (xin) v += xin_rows > 0 ? xin[(row % xin_rows) * od + c] : xin[idx];   // xin_rows > 0: one replica, read by all
     y[idx] = v;
   }
 }
@@ -732,6 +744,7 @@ GatK make_k(const ocean_gnn_shape* s, const GnnPlan& p, const int* const* graph,
   g.slope = s->negative_slope;
   g.att_drop.p = s->training ? s->dropout : 0.f;
   g.att_drop.seed = s->seed + 0x51ED270B7F4A7C15ull * (uint64_t)(2 * layer + 1);
+  g.z_shared = 0;
   return g;
 }
 DropoutP feat_drop(const ocean_gnn_shape* s, int layer) {
@@ -826,15 +839,21 @@ int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features, const in
   const int D = pl.D, H = pl.H, C = pl.C;
   const long rows = pl.rows;
   OCEAN_TRY(linear_fwd(node_features, s->G, params[0], params[1], ws + pl.x0, D, s->N, D, s->G, 1, st));
+  // Every replica starts from the same projected node features, so the first layer's linear transform and
+  // attention logits are computed once and shared (fast path); otherwise the features are replicated first.
+  const bool share0 = s->R > 1 && fast_edges(pl);
   const float* xin = ws + pl.x0;
-  if (s->R > 1) {
+  if (s->R > 1 && !share0) {
     hipLaunchKernelGGL(bcast_rows_kernel, dim3(egrid(rows * D)), dim3(256), 0, st, ws + pl.x0, ws + pl.xb, (long)s->N * D, s->R);
     OCEAN_LAUNCH_CHECK();
     xin = ws + pl.xb;
   }
   for (int l = 0; l < pl.layers; ++l) {
-    const GatK g = make_k(s, pl, graph, l);
-    OCEAN_TRY(linear_fwd(xin, D, params[pg_layer(l, 0)], nullptr, ws + pl.Z[l], D, (int)rows, D, D, 0, st));
+    GatK g = make_k(s, pl, graph, l);
+    const bool shared = share0 && l == 0;
+    g.z_shared = shared;
+    const int zrows = shared ? s->N : (int)rows;
+    OCEAN_TRY(linear_fwd(xin, D, params[pg_layer(l, 0)], nullptr, ws + pl.Z[l], D, zrows, D, D, 0, st));
     if (fast_edges(pl))
       GAT_STREAM_FAST(gat_scores_fast_kernel, ws + pl.Z[l], params[pg_layer(l, 1)], params[pg_layer(l, 2)], ws + pl.as_[l], ws + pl.ad[l]);
     else
@@ -851,7 +870,7 @@ int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features, const in
       OCEAN_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(gat_epilogue_kernel, dim3(egrid(rows * pl.out_dim[l])), dim3(256), 0, st, ws + pl.agg[l], params[pg_layer(l, 3)],
-                       pl.residual[l] ? xin : nullptr, ws + pl.y[l], rows, H, C, pl.concat[l], feat_drop(s, l));
+                       pl.residual[l] ? xin : nullptr, shared ? s->N : 0, ws + pl.y[l], rows, H, C, pl.concat[l], feat_drop(s, l));
     OCEAN_LAUNCH_CHECK();
     xin = ws + pl.y[l];
   }
@@ -876,9 +895,13 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
   OCEAN_TRY(linear_bwd_weight(dout, D, wf + pl.pooled, Cl, grads[pg_out(Lr, 0)], pl.P, D, Cl, st));
   OCEAN_TRY(colsum_add(dout, D, pl.P, D, grads[pg_out(Lr, 1)], st));
   OCEAN_TRY(linear_bwd_data(dout, D, params[pg_out(Lr, 0)], wb + pl.dpool, Cl, pl.P, D, Cl, 0, st));
+  const bool share0 = s->R > 1 && fast_edges(pl);
+  float* dx0 = wb + pl.dx0;
   for (int l = Lr - 1; l >= 0; --l) {
-    const GatK g = make_k(s, pl, graph, l);
-    const float* xin = l == 0 ? (s->R > 1 ? wf + pl.xb : wf + pl.x0) : wf + pl.y[l - 1];
+    GatK g = make_k(s, pl, graph, l);
+    const bool shared = share0 && l == 0;
+    g.z_shared = shared;
+    const float* xin = l == 0 ? (s->R > 1 && !share0 ? wf + pl.xb : wf + pl.x0) : wf + pl.y[l - 1];
     const bool last = (l == Lr - 1);
     const int od = pl.out_dim[l];
     const bool fast = fast_edges(pl);
@@ -924,6 +947,29 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
                          params[pg_layer(l, 1)], params[pg_layer(l, 2)], rows, H, C);
       OCEAN_LAUNCH_CHECK();
     }
+    if (shared) {
+      // one transform for all replicas: its gradients come from the replica sum of dZ, and the layer's input
+      // gradient is that sum times W plus (residual) the replica sum of the incoming output gradient
+      float* dzs = wb + pl.dagg;               // [N, D] scratch: dAgg is no longer needed at this point
+      const long per = (long)s->N * D;
+      const dim3 rg(ceil_div(per, 256), ceil_div(s->R, kReplicaChunk));
+      OCEAN_TRY(zero_f32(dzs, (size_t)per, st));
+      hipLaunchKernelGGL(sum_replicas_kernel, rg, dim3(256), 0, st, wb + pl.dZ, dzs, per, s->R);
+      OCEAN_LAUNCH_CHECK();
+      OCEAN_TRY(linear_bwd_weight(dzs, D, xin, D, grads[pg_layer(l, 0)], s->N, D, D, st));
+      OCEAN_TRY(zero_f32(dx0, (size_t)per, st));
+      if (pl.residual[l]) {
+        if (last) {   // a one-layer network: the incoming gradient is the mean-pool broadcast, materialised first
+          hipLaunchKernelGGL(bcast_pool_grad_kernel, dim3(egrid(rows * od)), dim3(256), 0, st, wb + pl.dpool, wb + pl.dY, rows, pl.pool_n, od,
+                             1.0f / (float)pl.pool_n);
+          OCEAN_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(sum_replicas_kernel, rg, dim3(256), 0, st, wb + pl.dY, dx0, per, s->R);
+        OCEAN_LAUNCH_CHECK();
+      }
+      OCEAN_TRY(linear_bwd_data(dzs, D, params[pg_layer(l, 0)], dx0, D, s->N, D, D, 1, st));
+      continue;
+    }
     OCEAN_TRY(linear_bwd_weight(wb + pl.dZ, D, xin, D, grads[pg_layer(l, 0)], (int)rows, D, D, st));
     // d(xin) = dZ . W (+ dY through the residual); written over dY for the next (earlier) layer
     if (pl.residual[l] && !last) {
@@ -939,8 +985,9 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
     }
   }
   // input projection: x0 = relu(W nf + b), shared by all replicas
-  float* dx0 = wb + pl.dx0;
-  if (s->R > 1) {
+  if (share0) {
+    // dx0 already holds the replica-summed gradient
+  } else if (s->R > 1) {
     OCEAN_TRY(zero_f32(dx0, (size_t)s->N * D, st));
     hipLaunchKernelGGL(sum_replicas_kernel, dim3(ceil_div((long)s->N * D, 256), ceil_div(s->R, kReplicaChunk)), dim3(256), 0, st,
                        wb + pl.dY, dx0, (long)s->N * D, s->R);

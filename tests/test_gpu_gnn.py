@@ -41,6 +41,7 @@ CASES = [  # N, G, D, H, layers, B, avg_deg
     (40, 12, 64, 1, 2, 2, 5.0),    # one head, one channel per lane
     (32, 8, 256, 8, 2, 2, 6.0),    # 4 channels per lane
     (24, 8, 512, 4, 1, 2, 5.0),    # 8 channels per lane
+    (20, 6, 64, 1, 1, 3, 4.0),     # one layer, one head: the pooled layer has the residual and the shared first transform
 ]
 
 
