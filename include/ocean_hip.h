@@ -77,6 +77,10 @@ typedef struct {
   float dropout;                             /* p of every nn.Dropout (dilated_cnn.py:58,175);
                                                 applied only when training                  */
   uint64_t seed;                             /* dropout mask seed of this forward/backward   */
+  const uint64_t* seed_epoch;                /* device counter folded into the seed inside the
+                                                kernels, or NULL: lets a captured HIP graph draw
+                                                fresh masks on every replay (bump it in between);
+                                                same meaning in every *_shape below            */
 } ocean_dcnn_shape;
 
 /* Parameter table order (pointers to device fp32):
@@ -131,6 +135,7 @@ typedef struct {
   float dropout;            /* feature and attention dropout p (graph_neural_network.py:191,218)       */
   float negative_slope;     /* LeakyReLU slope of GATConv (0.2)                                        */
   uint64_t seed;
+  const uint64_t* seed_epoch;
 } ocean_gnn_shape;
 
 /* params: [0] input_projection.weight [D,G] [1] .bias [D]; per layer l: lin.weight [D,D], att_src [D],
@@ -157,6 +162,7 @@ typedef struct {
   int training;
   float dropout, eps;       /* attention_dropout; LayerNorm eps (1e-5)               */
   uint64_t seed;
+  const uint64_t* seed_epoch;
 } ocean_mfa_shape;
 size_t ocean_mfa_fwd_workspace(const ocean_mfa_shape* s);
 size_t ocean_mfa_bwd_workspace(const ocean_mfa_shape* s);
@@ -181,6 +187,7 @@ typedef struct {
   int training, contrastive;
   float dropout, eps;
   uint64_t seed;
+  const uint64_t* seed_epoch;
 } ocean_fusion_shape;
 size_t ocean_fusion_fwd_workspace(const ocean_fusion_shape* s);
 size_t ocean_fusion_bwd_workspace(const ocean_fusion_shape* s);
@@ -220,6 +227,7 @@ typedef struct {
   int training;
   float dropout;            /* 0.1 hard-coded in the reference (ocean_model.py:117,120) */
   uint64_t seed;
+  const uint64_t* seed_epoch;
 } ocean_head_shape;
 size_t ocean_head_workspace(const ocean_head_shape* s);
 size_t ocean_head_bwd_workspace(const ocean_head_shape* s);
@@ -260,6 +268,13 @@ int ocean_grad_sqnorm(const ocean_adam_chunk* table, int n_chunks, double* sqnor
 int ocean_clip_adam_step(const ocean_adam_chunk* table, int n_chunks, const double* sqnorm, float max_norm,
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          int write_clipped, void* stream);
+/* Same update with the learning rate (float[1]) and the 1-based step count (int[1]) read from device memory, so
+   that the launch can sit in a captured HIP graph and still follow the host's learning-rate policy and the bias
+   correction of torch.optim.Adam (online_learner.py:256-261): the caller rewrites lr_dev / increments step_dev
+   between replays.  No counterpart in the reference (it launches every kernel eagerly). */
+int ocean_clip_adam_step_dev(const ocean_adam_chunk* table, int n_chunks, const double* sqnorm, float max_norm,
+                             const float* lr_dev, const int* step_dev, float beta1, float beta2, float eps,
+                             float weight_decay, int write_clipped, void* stream);
 
 /* ------------------------------------------------------------------ kernel timing (measurement aid)
  * No counterpart in the reference.  While enabled, every GEMM launch is bracketed by HIP events on its

@@ -31,7 +31,9 @@ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 // ---------------------------------------------------------------- dropout
 // Counter-based dropout: element `idx` of a site is kept iff hash(seed, idx) >= p,
 // so forward and backward regenerate the same mask without storing it.
-struct DropoutP { float p; uint64_t seed; };
+// `epoch` (device pointer or null) is added into the seed inside the kernel: a captured HIP graph replays the same
+// kernel arguments, so a launch-time seed alone would repeat the masks; the caller bumps *epoch between replays.
+struct DropoutP { float p; uint64_t seed; const uint64_t* epoch; };
 
 // 32-bit multiply-xorshift mixer over (seed, idx); integer multiplies run at a quarter of the fp32 rate on
 // CDNA, so the hash is kept to four of them.
@@ -45,6 +47,14 @@ __host__ __device__ inline uint32_t ocean_hash32(uint64_t seed, uint64_t idx) {
   h ^= h >> 15;
   return h;
 }
+#ifdef __HIPCC__
+// fold *epoch into the seed once, at kernel entry (kernels take DropoutP by value)
+__device__ __forceinline__ DropoutP dropout_resolve(DropoutP d) {
+  if (d.p > 0.f && d.epoch != nullptr) d.seed += d.epoch[0] * 0xD1B54A32D192ED03ull;
+  d.epoch = nullptr;
+  return d;
+}
+#endif
 // multiplier applied to a surviving / dropped activation: 1/(1-p) or 0
 __host__ __device__ inline float dropout_keep(const DropoutP& d, uint64_t idx) {
   const float u = (float)(ocean_hash32(d.seed, idx) >> 8) * (1.0f / 16777216.0f);   // [0,1)

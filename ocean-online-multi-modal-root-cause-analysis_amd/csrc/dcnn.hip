@@ -155,6 +155,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restrict__ u, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ res,
                                                            float* __restrict__ out, int M, int C, ColTile ct, DropoutP dp) {
+  dp = dropout_resolve(dp);
   const int W = 1 << ct.wlog;
   const int tx = threadIdx.x & (W - 1), ty = threadIdx.x >> ct.wlog, RL = 256 >> ct.wlog;
   const int c0 = (blockIdx.x * W + tx) * VEC;
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ shift, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, double* __restrict__ bslots,
                                                             int M, int C, ColTile ct, DropoutP dp) {
+  dp = dropout_resolve(dp);
   __shared__ float red[2][256 * VEC];
   const int W = 1 << ct.wlog;
   const int tx = threadIdx.x & (W - 1), ty = threadIdx.x >> ct.wlog, RL = 256 >> ct.wlog;
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const double* __restrict__ bstats,
                                                            double n, float* __restrict__ du, int M, int C, int training,
                                                            ColTile ct, DropoutP dp) {
+  dp = dropout_resolve(dp);
   const int W = 1 << ct.wlog;
   const int tx = threadIdx.x & (W - 1), ty = threadIdx.x >> ct.wlog, RL = 256 >> ct.wlog;
   const int c0 = (blockIdx.x * W + tx) * VEC;
@@ -352,6 +355,7 @@ inline DropoutP layer_dropout(const ocean_dcnn_shape* s, int j) {
   DropoutP dp;
   dp.p = s->training ? s->dropout : 0.f;
   dp.seed = s->seed + 0x9E3779B97F4A7C15ull * (uint64_t)(j + 1);
+  dp.epoch = s->seed_epoch;
   return dp;
 }
 

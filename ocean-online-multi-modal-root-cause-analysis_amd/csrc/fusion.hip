@@ -17,6 +17,7 @@ constexpr int kTok = 3;
 // qkv [B*3, 3E] rows (b,l): [q | k | v].  probs [B,H,3,3] post-softmax (pre-dropout).  o [B*3, E].
 __global__ void mha3_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ probs, float* __restrict__ o,
                                 int B, int E, int H, DropoutP dp) {
+  dp = dropout_resolve(dp);
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * H) return;
   const int b = idx / H, h = idx % H, dh = E / H;
@@ -61,6 +62,7 @@ __global__ void mha3_fwd_kernel(const float* __restrict__ qkv, float* __restrict
 // dOm [B,E]: gradient of the token mean (each token receives dOm/3).  dqkv [B*3, 3E].
 __global__ void mha3_bwd_kernel(const float* __restrict__ dOm, const float* __restrict__ qkv, const float* __restrict__ probs,
                                 float* __restrict__ dqkv, int B, int E, int H, DropoutP dp) {
+  dp = dropout_resolve(dp);
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * H) return;
   const int b = idx / H, h = idx % H, dh = E / H;
@@ -139,6 +141,7 @@ DropoutP site(const ocean_fusion_shape* s, int id) {
   DropoutP d;
   d.p = s->training ? s->dropout : 0.f;
   d.seed = s->seed + 0xD6E8FEB86659FD93ull * (uint64_t)(id + 1);
+  d.epoch = s->seed_epoch;
   return d;
 }
 
@@ -169,7 +172,7 @@ int ocean_fusion_fwd(const ocean_fusion_shape* s, const float* t, const float* s
   const size_t BE = (size_t)B * E;
   const float* xin[3] = {t, sp, lg};
   const int xd[3] = {s->td, s->sd, s->ld};
-  const DropoutP none = {0.f, 0};
+  const DropoutP none = {0.f, 0, nullptr};
   // the three modality branches run as one launch per layer
   LinFwd l[3];
   for (int m = 0; m < 3; ++m) l[m] = LinFwd{xin[m], xd[m], P_[4 * m], P_[4 * m + 1], ws + pl.R + m * BE, E, B, E, xd[m]};
@@ -210,7 +213,7 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* s
   hipStream_t st = (hipStream_t)stream;
   const int B = s->B, E = s->E, Pd = s->Pd;
   const size_t BE = (size_t)B * E;
-  const DropoutP none = {0.f, 0};
+  const DropoutP none = {0.f, 0, nullptr};
   float* e1 = wb + pl.e1; float* e2 = wb + pl.e2; float* dX = wb + pl.dX;
   if (dfused) {
     OCEAN_TRY(lin_bwd(wf + pl.H1, E, dfused, E, B, E, E, P_[20], G_[20], G_[21], e2, E, 0, st));

@@ -109,6 +109,7 @@ template <int CPL>
 __global__ __launch_bounds__(256) void gat_aggregate_kernel(GatK g, const float* __restrict__ Z, const float* __restrict__ a_s,
                                                             const float* __restrict__ a_d, float* __restrict__ agg,
                                                             float* __restrict__ smax, float* __restrict__ sden) {
+  g.att_drop = dropout_resolve(g.att_drop);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long node = (long)blockIdx.x * kWavesPerBlock + wave;
   if (node >= (long)g.R * g.N) return;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_fast_kernel(GatK g, int hlo
                                                                  const float* __restrict__ a_s, const float* __restrict__ a_d,
                                                                  float* __restrict__ agg, float* __restrict__ smax,
                                                                  float* __restrict__ sden) {
+  g.att_drop = dropout_resolve(g.att_drop);
   __shared__ float wl_all[kWavesPerBlock][64];
   __shared__ int jl_all[kWavesPerBlock][64];
   __shared__ float dl_all[kWavesPerBlock][16];
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(256) void gat_bwd_source_fast_kernel(GatK g, int hl
                                                                   const float* __restrict__ dagg, const float* __restrict__ Dn,
                                                                   float* __restrict__ dZ, float* __restrict__ da_s,
                                                                   float* __restrict__ da_d) {
+  g.att_drop = dropout_resolve(g.att_drop);
   __shared__ float wl_all[kWavesPerBlock][64];
   __shared__ float hl_all[kWavesPerBlock][64];
   __shared__ int il_all[kWavesPerBlock][64];
@@ -415,6 +418,8 @@ __global__ __launch_bounds__(256) void gat_bwd_prep_fast_kernel(GatK g, int hlog
                                                                 const float* __restrict__ bias, float* __restrict__ dagg,
                                                                 float* __restrict__ Dn, float* __restrict__ bias_slots,
                                                                 int concat, DropoutP fd) {
+  fd = dropout_resolve(fd);
+  fd = dropout_resolve(fd);
   __shared__ float red[kWavesPerBlock * 64 * CPL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = g.H, C = g.C, LPH = 64 >> hlog, hk = lane >> (6 - hlog), c0 = lane * CPL;
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(256) void gat_bwd_att_fast_kernel(GatK g, int hlog,
 // y = dropout(relu(headmix(agg) + bias)) (+ xin), headmix = identity (concat) or mean over heads
 __global__ void gat_epilogue_kernel(const float* __restrict__ agg, const float* __restrict__ bias, const float* __restrict__ xin,
                                     int xin_rows, float* __restrict__ y, long rows, int H, int C, int concat, DropoutP fd) {
+  fd = dropout_resolve(fd);
   const int od = concat ? H * C : C;
   const long n = rows * od;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
@@ -518,6 +524,7 @@ __global__ void gat_epilogue_kernel(const float* __restrict__ agg, const float* 
 __global__ void gat_bwd_epilogue_kernel(const float* __restrict__ dy, int dy_bcast_N, float dy_scale, const float* __restrict__ agg,
                                         const float* __restrict__ bias, float* __restrict__ dagg, long rows, int H, int C,
                                         int concat, DropoutP fd) {
+  fd = dropout_resolve(fd);
   const int od = concat ? H * C : C;
   const long n = rows * od;
   for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
@@ -564,6 +571,7 @@ __global__ __launch_bounds__(256) void gat_bwd_source_kernel(GatK g, const float
                                                              const float* __restrict__ sden, const float* __restrict__ dagg,
                                                              const float* __restrict__ Dn, float* __restrict__ dZ,
                                                              float* __restrict__ da_s, float* __restrict__ da_d) {
+  g.att_drop = dropout_resolve(g.att_drop);
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* wl = lds + wave * (g.HC + g.H);
@@ -744,6 +752,7 @@ GatK make_k(const ocean_gnn_shape* s, const GnnPlan& p, const int* const* graph,
   g.slope = s->negative_slope;
   g.att_drop.p = s->training ? s->dropout : 0.f;
   g.att_drop.seed = s->seed + 0x51ED270B7F4A7C15ull * (uint64_t)(2 * layer + 1);
+  g.att_drop.epoch = s->seed_epoch;
   g.z_shared = 0;
   return g;
 }
@@ -751,6 +760,7 @@ DropoutP feat_drop(const ocean_gnn_shape* s, int layer) {
   DropoutP d;
   d.p = s->training ? s->dropout : 0.f;
   d.seed = s->seed + 0x51ED270B7F4A7C15ull * (uint64_t)(2 * layer + 2);
+  d.epoch = s->seed_epoch;
   return d;
 }
 

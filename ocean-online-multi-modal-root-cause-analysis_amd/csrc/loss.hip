@@ -272,6 +272,7 @@ static DropoutP head_site(const ocean_head_shape* s, int id) {
   DropoutP d;
   d.p = s->training ? s->dropout : 0.f;
   d.seed = s->seed + 0xC2B2AE3D27D4EB4Full * (uint64_t)(id + 1);
+  d.epoch = s->seed_epoch;
   return d;
 }
 

@@ -180,6 +180,7 @@ DropoutP site(const ocean_mfa_shape* s, int id) {
   DropoutP d;
   d.p = s->training ? s->dropout : 0.f;
   d.seed = s->seed + 0xA24BAED4963EE407ull * (uint64_t)(id + 1);
+  d.epoch = s->seed_epoch;
   return d;
 }
 
@@ -210,7 +211,7 @@ int ocean_mfa_fwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
   const size_t BW = (size_t)B * W;
   const float* xin[3] = {t, sp, lg};
   const int xd[3] = {s->td, s->sd, s->ld};
-  const DropoutP none = {0.f, 0};
+  const DropoutP none = {0.f, 0, nullptr};
   // the three modality branches run as one launch per layer; dropout sites cover all three (contiguous [3, B, W])
   LinFwd l[3];
   for (int m = 0; m < 3; ++m) l[m] = LinFwd{xin[m], xd[m], P_[2 * m], P_[2 * m + 1], ws + pl.P + m * BW, W, B, W, xd[m]};
@@ -248,7 +249,7 @@ int ocean_mfa_bwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
   hipStream_t st = (hipStream_t)stream;
   const int B = s->B, W = s->W, Wh = pl.Wh;
   const size_t BW = (size_t)B * W;
-  const DropoutP none = {0.f, 0};
+  const DropoutP none = {0.f, 0, nullptr};
   float* e1 = wb + pl.e1; float* e2 = wb + pl.e2; float* d1 = wb + pl.d1; float* d2 = wb + pl.d2;
   // output LayerNorm and MLP
   OCEAN_TRY(layernorm_bwd(dout, W, wf + pl.O2, W, wf + pl.lnso, P_[24], e1, W, G_[24], G_[25], B, W, none, st));

@@ -33,7 +33,14 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const ocean_adam_chunk* __r
 
 __global__ __launch_bounds__(256) void clip_adam_kernel(const ocean_adam_chunk* __restrict__ tab, const double* __restrict__ sqnorm,
                                                         float max_norm, float lr, float b1, float b2, float eps, float wd,
-                                                        float bc1, float bc2, int write_clipped) {
+                                                        float bc1, float bc2, int write_clipped,
+                                                        const float* __restrict__ lr_dev, const int* __restrict__ step_dev) {
+  if (lr_dev != nullptr) {     // learning rate and step count live on the device (HIP-graph replays)
+    lr = lr_dev[0];
+    const float t = (float)step_dev[0];
+    bc1 = 1.0f - powf(b1, t);
+    bc2 = 1.0f - powf(b2, t);
+  }
   const ocean_adam_chunk c = tab[blockIdx.x];
   float* p = reinterpret_cast<float*>(c.param);
   float* g = reinterpret_cast<float*>(c.grad);
@@ -72,7 +79,18 @@ int ocean_clip_adam_step(const ocean_adam_chunk* table, int n_chunks, const doub
   if (n_chunks <= 0 || step < 1) return OCEAN_ERR_BAD_SHAPE;
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, sqnorm, max_norm, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2, write_clipped);
+                     weight_decay, bc1, bc2, write_clipped, (const float*)nullptr, (const int*)nullptr);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int ocean_clip_adam_step_dev(const ocean_adam_chunk* table, int n_chunks, const double* sqnorm, float max_norm, const float* lr_dev,
+                             const int* step_dev, float beta1, float beta2, float eps, float weight_decay, int write_clipped,
+                             void* stream) {
+  if (!table || !lr_dev || !step_dev) return OCEAN_ERR_NULL;
+  if (n_chunks <= 0) return OCEAN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, sqnorm, max_norm, 0.f, beta1, beta2, eps,
+                     weight_decay, 1.f, 1.f, write_clipped, lr_dev, step_dev);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }

@@ -19,6 +19,7 @@ struct LnFwdBatch { LnFwdSet s[kLnSets]; };
 struct LnBwdBatch { LnBwdSet s[kLnSets]; };
 
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdBatch batch, int ldx, int ldy, int rows, int W, float eps, DropoutP dp) {
+  dp = dropout_resolve(dp);
   const LnFwdSet& st = batch.s[blockIdx.y];
   const float* __restrict__ x = st.x;
   const float* __restrict__ gamma = st.gamma;
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdBatch batch, int
 constexpr int kLnRowsPerBlock = 32;
 constexpr int kMaxColsPerLane = 16;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdBatch batch, int lddy, int ldx, int lddx, int rows, int W, DropoutP dp) {
+  dp = dropout_resolve(dp);
   const LnBwdSet& st = batch.s[blockIdx.y];
   const float* __restrict__ dy = st.dy;
   const float* __restrict__ x = st.x;
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 }
 
 __global__ void dropout_kernel(float* __restrict__ x, int ld, int M, int N, int group, DropoutP d) {
+  d = dropout_resolve(d);
   const long n = (long)M * N;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / N), c = (int)(i % N);

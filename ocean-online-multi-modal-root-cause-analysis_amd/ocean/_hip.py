@@ -30,13 +30,13 @@ class DcnnShape(ctypes.Structure):
                 ("channels", c_int * MAX_CONV_LAYERS), ("dilations", c_int * MAX_CONV_LAYERS),
                 ("kernel_size", c_int), ("out_dim", c_int), ("training", c_int),
                 ("eps", c_float), ("momentum", c_float), ("bn_count", c_long),
-                ("dropout", c_float), ("seed", c_uint64)]
+                ("dropout", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
 
 
 class GnnShape(ctypes.Structure):
     _fields_ = [("N", c_int), ("R", c_int), ("G", c_int), ("D", c_int), ("H", c_int), ("layers", c_int),
                 ("E", c_int), ("pool_n", c_int), ("training", c_int), ("dropout", c_float),
-                ("negative_slope", c_float), ("seed", c_uint64)]
+                ("negative_slope", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
 
 
 def _declare(lib) -> None:
@@ -65,13 +65,13 @@ def _declare(lib) -> None:
 
 class MfaShape(ctypes.Structure):
     _fields_ = [("B", c_int), ("td", c_int), ("sd", c_int), ("ld", c_int), ("W", c_int), ("heads", c_int),
-                ("training", c_int), ("dropout", c_float), ("eps", c_float), ("seed", c_uint64)]
+                ("training", c_int), ("dropout", c_float), ("eps", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
 
 
 class FusionShape(ctypes.Structure):
     _fields_ = [("B", c_int), ("td", c_int), ("sd", c_int), ("ld", c_int), ("E", c_int), ("Pd", c_int),
                 ("heads", c_int), ("training", c_int), ("contrastive", c_int), ("dropout", c_float),
-                ("eps", c_float), ("seed", c_uint64)]
+                ("eps", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
 
 
 class InfoNceShape(ctypes.Structure):
@@ -81,7 +81,7 @@ class InfoNceShape(ctypes.Structure):
 
 class HeadShape(ctypes.Structure):
     _fields_ = [("B", c_int), ("E", c_int), ("h1", c_int), ("h2", c_int), ("S", c_int), ("training", c_int),
-                ("dropout", c_float), ("seed", c_uint64)]
+                ("dropout", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
 
 
 class AdamChunk(ctypes.Structure):
@@ -126,6 +126,7 @@ def _declare_rest(lib) -> None:
     sig("ocean_prof_summary", c_int, ctypes.c_char_p, c_size_t)
     sig("ocean_grad_sqnorm", c_int, vp, c_int, vp, vp)
     sig("ocean_clip_adam_step", c_int, vp, c_int, vp, c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_int, vp)
+    sig("ocean_clip_adam_step_dev", c_int, vp, c_int, vp, c_float, vp, vp, c_float, c_float, c_float, c_float, c_int, vp)
 
 
 def _declare_gnn(lib) -> None:
@@ -181,6 +182,22 @@ def ptr_table(tensors: Sequence[Optional[torch.Tensor]], name: str):
     for i, t in enumerate(tensors):
         arr[i] = dev_ptr(t, f"{name}[{i}]").value if t is not None else None
     return arr
+
+
+_epochs = {}
+
+
+def seed_epoch(device) -> torch.Tensor:
+    """The per-device dropout epoch counter (int64[1], starts at 0).  Every kernel that draws a dropout mask adds
+    it into its seed on the device, so a captured HIP graph - whose kernel arguments, seeds included, are frozen -
+    still draws new masks on each replay once the replay increments the counter."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _epochs.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=device)
+        _epochs[key] = t
+    return t
 
 
 def new_seed(p: float) -> int:

@@ -180,7 +180,8 @@ class DilatedCNN(nn.Module):
         s.bn_count = x.shape[0] * x.shape[1] * (self.stats_world_size if self.stats_all_reduce else 1)
         p = self.conv_layers[0].dropout.p if self.training else 0.0
         s.dropout = p
-        s.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
+        s.seed = _hip.new_seed(p)
+        s.seed_epoch = _hip.seed_epoch(x.device).data_ptr() if p > 0 else None
         return s
 
     @staticmethod

@@ -218,6 +218,7 @@ class GraphFusionModule(nn.Module):
         sh.dropout = float(self.output_projection[2].p) if self.training else 0.0
         sh.eps = self.attention_norm.eps
         sh.seed = _hip.new_seed(sh.dropout)
+        sh.seed_epoch = _hip.seed_epoch(t.device).data_ptr() if sh.dropout > 0 else None
         return sh
 
     def forward(self, temporal_features: torch.Tensor, spatial_features: torch.Tensor, log_features: torch.Tensor,

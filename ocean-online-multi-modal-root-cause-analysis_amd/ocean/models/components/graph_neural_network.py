@@ -161,7 +161,8 @@ class GraphNeuralNetwork(nn.Module):
         s.training = int(self.training)
         s.dropout = self._dropout_p()
         s.negative_slope = self.conv_layers[0].negative_slope
-        s.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if s.dropout > 0 else 0
+        s.seed = _hip.new_seed(s.dropout)
+        s.seed_epoch = _hip.seed_epoch(node_features.device).data_ptr() if s.dropout > 0 else None
         return s
 
     def _check_supported(self):

@@ -157,6 +157,7 @@ class MultiFactorAttention(nn.Module):
         sh.dropout = float(self.output_projection[2].p) if self.training else 0.0
         sh.eps = self.layer_norms["output"].eps
         sh.seed = _hip.new_seed(sh.dropout)
+        sh.seed_epoch = _hip.seed_epoch(t.device).data_ptr() if sh.dropout > 0 else None
         return sh
 
     def forward(self, temporal_features: torch.Tensor, spatial_features: torch.Tensor, log_features: torch.Tensor,

@@ -36,6 +36,7 @@ class _HeadFunction(torch.autograd.Function):
         sh.h1, sh.h2, sh.S = params[0].shape[0], params[2].shape[0], params[4].shape[0]
         sh.training, sh.dropout = int(training), (p_drop if training else 0.0)
         sh.seed = _hip.new_seed(sh.dropout)
+        sh.seed_epoch = _hip.seed_epoch(x.device).data_ptr() if sh.dropout > 0 else None
         ctx.set_materialize_grads(False)
         ws = torch.empty(L.ocean_head_workspace(ctypes.byref(sh)), device=x.device, dtype=torch.float32)
         logits = torch.empty(sh.B, sh.S, device=x.device, dtype=torch.float32)

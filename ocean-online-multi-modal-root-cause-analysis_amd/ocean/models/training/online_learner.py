@@ -20,6 +20,7 @@ import numpy as np
 import torch
 import torch.optim as optim
 
+from ... import _hip
 from ...configs import OCEANConfig
 from ...data.data_types import DatasetSample
 from ...optim import FusedAdam
@@ -129,6 +130,54 @@ class AdaptiveLearningRateScheduler:
         self.performance_history.clear()
 
 
+class _GraphedStep:
+    """One update step (forward, loss, backward, clip + Adam) recorded as a HIP graph for a fixed batch shape and
+    service graph, and replayed with one launch.  The recorded kernels keep their arguments, so everything that
+    must change between steps lives in device memory: the inputs (copied into static buffers before a replay),
+    the dropout epoch counter every mask-drawing kernel adds to its seed, and the optimizer's learning rate and
+    step count.  The reference has no counterpart (it launches ~10^3 kernels per step from Python)."""
+
+    def __init__(self, learner: "OnlineLearner", metrics, service_graph, logs, labels):
+        model, opt = learner.model, learner.optimizer
+        dev = model.device
+        if opt._step_dev is None:
+            opt.make_capturable(dev)
+        self.metrics = metrics.detach().to(dev, torch.float32).clone()
+        self.logs = logs.detach().to(dev, torch.float32).clone()
+        self.labels = labels.detach().to(dev, torch.float32).clone()
+        self.service_graph = service_graph
+        self.epoch = _hip.seed_epoch(dev)
+        clip = learner.config.training.gradient_clip_norm
+        opt.zero_grad(set_to_none=True)            # gradients are re-created inside the graph's memory pool
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.epoch.add_(1)
+            outputs = model(self.metrics, service_graph, self.logs)
+            losses = model.compute_loss(outputs, self.labels)
+            losses["total_loss"].backward()
+            opt.step(max_norm=clip if clip > 0 else 0.0)
+            self.keys = [k for k in ("total_loss", "prediction_loss", "contrastive_loss") if torch.is_tensor(losses.get(k))]
+            self.loss_vec = torch.stack([losses[k].detach().float().reshape(()) for k in self.keys])
+        self.outputs = outputs
+        # recording advanced the host-side step counters without running anything: undo that
+        for st in opt.state.values():
+            if st:
+                st["step"] -= 1
+        # buffers the recorded copy nodes and kernels read on every replay
+        self._keep = (opt._table_host, opt._table, opt._sq)
+
+    def replay(self, learner: "OnlineLearner", metrics, logs, labels) -> Dict[str, float]:
+        self.metrics.copy_(metrics, non_blocking=True)
+        self.logs.copy_(logs, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+        learner.optimizer.sync_lr()               # a learning rate the host changed since the last step
+        self.graph.replay()
+        learner.optimizer.after_replay()
+        learner.update_count += 1
+        return dict(zip(self.keys, self.loss_vec.cpu().tolist()))
+
+
 class OnlineLearner:
     def __init__(self, model: OCEANModel, config: OCEANConfig, optimizer: Optional[optim.Optimizer] = None):
         self.model, self.config = model, config
@@ -146,6 +195,11 @@ class OnlineLearner:
         self.stream_thread: Optional[threading.Thread] = None
         # data-parallel hook: called with the list of parameters after backward, before the update
         self.grad_sync = None
+        # use_hip_graph: after two eager steps with the same batch shape and graph, process_tensors records the
+        # step as a HIP graph and replays it from then on (single-GPU, FusedAdam, in-batch contrastive mode)
+        self.use_hip_graph = False
+        self._graphed: Dict[Any, _GraphedStep] = {}
+        self._graph_seen: Dict[Any, int] = defaultdict(int)
 
     # ------------------------------------------------------------------ the update step
     def _losses_to_host(self, losses: Dict[str, Any]) -> Dict[str, float]:
@@ -206,15 +260,41 @@ class OnlineLearner:
         """process_batch on already-collated tensors ([B,T,F], graph, [B,768], [B,S]); tensors that
         already live on the model's device are used in place (no host staging)."""
         self.model.train()
-        outputs = self.model(metrics, service_graph, logs)
-        losses = self.model.compute_loss(outputs, labels.to(self.model.device, non_blocking=True))
-        self._apply_update(losses["total_loss"])
-        host = self._losses_to_host(losses)
+        host = self._graph_step(metrics, service_graph, logs, labels) if self.use_hip_graph else None
+        if host is None:
+            outputs = self.model(metrics, service_graph, logs)
+            losses = self.model.compute_loss(outputs, labels.to(self.model.device, non_blocking=True))
+            self._apply_update(losses["total_loss"])
+            host = self._losses_to_host(losses)
         current_lr = self.lr_scheduler.step(host["total_loss"], self.optimizer)
         self.performance_history["batch_loss"].append(host["total_loss"])
         self.performance_history["learning_rate"].append(current_lr)
         return {"batch_loss": host["total_loss"], "batch_prediction_loss": host["prediction_loss"],
                 "batch_size": int(metrics.shape[0]), "learning_rate": current_lr, "update_count": self.update_count}
+
+    def _graph_step(self, metrics, service_graph, logs, labels) -> Optional[Dict[str, float]]:
+        """Replay (or, on the third step with one signature, record) the HIP graph of this update; None when the
+        step has to run eagerly."""
+        if (self.grad_sync is not None or not isinstance(self.optimizer, FusedAdam) or self.model.device.type != "cuda"
+                or self.model.contrastive_negatives != "in_batch"):
+            return None
+        adj = service_graph.adjacency_matrix
+        key = (tuple(metrics.shape), tuple(logs.shape), tuple(labels.shape), id(service_graph), adj._version,
+               service_graph.node_features._version)
+        step = self._graphed.get(key)
+        if step is None:
+            self._graph_seen[key] += 1
+            if self._graph_seen[key] <= 2:
+                return None
+            try:
+                step = _GraphedStep(self, metrics, service_graph, logs, labels)
+            except Exception as e:      # keep training eagerly if this step cannot be recorded
+                logger.warning("HIP graph capture failed (%s); continuing without it", e)
+                self.use_hip_graph = False
+                self.optimizer.zero_grad(set_to_none=True)
+                return None
+            self._graphed[key] = step
+        return step.replay(self, metrics, logs, labels)
 
     def experience_replay(self, replay_batch_size: int = 32) -> Optional[Dict[str, float]]:
         if len(self.memory_buffer) < replay_batch_size:

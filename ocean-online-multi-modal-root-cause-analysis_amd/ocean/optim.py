@@ -28,6 +28,11 @@ class FusedAdam(torch.optim.Optimizer):
         self._n_chunks = 0
         self._sq = None
         self.last_grad_norm: Optional[torch.Tensor] = None      # device scalar, set when max_norm is given
+        # HIP-graph support: learning rate and step count mirrored in device memory (see make_capturable)
+        self._lr_dev: Optional[torch.Tensor] = None
+        self._step_dev: Optional[torch.Tensor] = None
+        self._lr_host: Optional[float] = None
+        self._table_host = None
 
     def _build_table(self, entries, device):
         rows = []
@@ -37,8 +42,36 @@ class FusedAdam(torch.optim.Optimizer):
                 c = min(_CHUNK, n - base)
                 rows.append((p.data_ptr() + 4 * base, g.data_ptr() + 4 * base, m.data_ptr() + 4 * base, v.data_ptr() + 4 * base, c))
                 base += c
-        t = torch.tensor(rows, dtype=torch.int64).to(device, non_blocking=True)   # 5 x int64 per row == ocean_adam_chunk
-        return t, len(rows)
+        # pinned staging + asynchronous copy: legal inside a stream capture, where it becomes a copy node that
+        # re-reads this host buffer on every replay (so the buffer is kept alive)
+        self._table_host = torch.tensor(rows, dtype=torch.int64).pin_memory()    # 5 x int64 per row == ocean_adam_chunk
+        return self._table_host.to(device, non_blocking=True), len(rows)
+
+    def make_capturable(self, device) -> None:
+        """Keep the learning rate and the step count in device memory so that step() can be recorded into a HIP
+        graph (torch.cuda.graph) and replayed: the kernels then read them instead of launch-time constants.
+        All parameters must share one step count (they do unless parameters were added mid-training)."""
+        steps = {int(st["step"]) for st in self.state.values() if st}
+        if len(steps) > 1:
+            raise _hip.OceanHipError("capturable FusedAdam needs one common step count")
+        self._step_dev = torch.full((1,), steps.pop() if steps else 0, dtype=torch.int32, device=device)
+        self._lr_host = float(self.param_groups[0]["lr"])
+        self._lr_dev = torch.full((1,), self._lr_host, dtype=torch.float32, device=device)
+
+    def after_replay(self) -> None:
+        """Host bookkeeping after one graph replay of step(): advance the per-parameter step counters kept for
+        state_dict() and push a changed learning rate to the device."""
+        for st in self.state.values():
+            if st:
+                st["step"] += 1
+        self.sync_lr()
+
+    def sync_lr(self) -> None:
+        if self._lr_dev is not None:
+            lr = float(self.param_groups[0]["lr"])
+            if lr != self._lr_host:
+                self._lr_dev.fill_(lr)
+                self._lr_host = lr
 
     @torch.no_grad()
     def step(self, closure=None, max_norm: float = 0.0, write_clipped: bool = True):
@@ -46,6 +79,8 @@ class FusedAdam(torch.optim.Optimizer):
         min(1, max_norm / (global_norm + 1e-6)) like clip_grad_norm_."""
         loss = closure() if closure is not None else None
         L = _hip.lib()
+        if self._lr_dev is not None and not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
         for group in self.param_groups:
             by_step = {}
             for p in group["params"]:
@@ -85,6 +120,16 @@ class FusedAdam(torch.optim.Optimizer):
                 sq_ptr = ctypes.c_void_p(self._sq.data_ptr())
                 self.last_grad_norm = self._sq
             b1, b2 = group["betas"]
+            if self._step_dev is not None:
+                if len(by_step) != 1 or len(self.param_groups) != 1:
+                    raise _hip.OceanHipError("capturable FusedAdam needs one parameter group and one common step count")
+                self._step_dev.add_(1)
+                _hip.check(L.ocean_clip_adam_step_dev(ctypes.c_void_p(self._table.data_ptr()), self._n_chunks, sq_ptr,
+                                                      float(max_norm or 0.0), ctypes.c_void_p(self._lr_dev.data_ptr()),
+                                                      ctypes.c_void_p(self._step_dev.data_ptr()), float(b1), float(b2),
+                                                      float(group["eps"]), float(group["weight_decay"]), int(write_clipped),
+                                                      _hip.stream()), "ocean_clip_adam_step_dev")
+                continue
             for (pos, n), k in zip(self._ranges, sorted(by_step)):
                 _hip.check(L.ocean_clip_adam_step(ctypes.c_void_p(self._table.data_ptr() + 40 * pos), n, sq_ptr, float(max_norm or 0.0),
                                                   float(group["lr"]), float(b1), float(b2), float(group["eps"]),

@@ -1,0 +1,122 @@
+"""The HIP-graph replay of the online update step must be the same computation as the eagerly launched step.
+
+With dropout off the two are compared step by step (same kernels, same order: losses to 1e-5, parameters and Adam
+state within the fp32 noise Adam amplifies); with dropout on, replays must draw fresh masks (the recorded seeds are
+frozen, the device epoch counter is not), follow the host's learning-rate changes, and keep the optimizer's step
+counters in line with the number of updates.
+"""
+import pytest
+import torch
+
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg():
+    import ocean
+    cfg = ocean.OCEANConfig()
+    cfg.model.dcnn_channels, cfg.model.dcnn_dilation_rates = [8, 16], [1, 2]
+    cfg.model.hidden_dim = cfg.model.attention_dim = 16
+    cfg.model.attention_num_heads, cfg.model.gnn_num_heads = 4, 2
+    cfg.model.fusion_projection_dim, cfg.model.num_services = 32, 6
+    cfg.data.metrics_features, cfg.data.log_embedding_dim, cfg.data.graph_features = 5, 24, 7
+    return cfg
+
+
+def _learner(dropout_off, use_graph, negatives="in_batch"):
+    import ocean
+    from ocean.models.training import OnlineLearner
+    cfg = _cfg()
+    m = ocean.OCEANModel(cfg)
+    m.load_state_dict(synth.fill_state_dict(m.state_dict(), 3))
+    if dropout_off:
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+    m = m.cuda()
+    m.contrastive_negatives = negatives
+    learner = OnlineLearner(m, cfg)
+    learner.use_hip_graph = use_graph
+    return m, learner
+
+
+def _data(i, B=4, T=12):
+    from ocean.data import ServiceGraph
+    g = lambda s: torch.Generator().manual_seed(s)
+    metrics, logs = torch.randn(B, T, 5, generator=g(10 + i)).cuda(), torch.randn(B, 24, generator=g(20 + i)).cuda()
+    labels = torch.zeros(B, 6)
+    labels[torch.arange(B), torch.randint(0, 6, (B,), generator=g(30 + i))] = 1.0
+    return metrics, logs, labels.cuda()
+
+
+def _graph():
+    from ocean.data import ServiceGraph
+    adj = synth.random_digraph(6, 2.0, 4)
+    return ServiceGraph(adjacency_matrix=adj, node_features=torch.randn(6, 7, generator=torch.Generator().manual_seed(1)))
+
+
+def test_replay_matches_eager_steps():
+    sg = _graph()
+    runs = {}
+    for use_graph in (False, True):
+        m, learner = _learner(True, use_graph)
+        losses = []
+        for i in range(7):
+            metrics, logs, labels = _data(i)
+            losses.append(learner.process_tensors(metrics, sg, logs, labels))
+        assert len(learner._graphed) == (1 if use_graph else 0)
+        runs[use_graph] = (losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, learner)
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert a["update_count"] == b["update_count"]
+        assert abs(a["batch_loss"] - b["batch_loss"]) <= 1e-5 * max(1.0, abs(a["batch_loss"]))
+        assert abs(a["batch_prediction_loss"] - b["batch_prediction_loss"]) <= 1e-5
+    for k, v in runs[False][1].items():
+        w = runs[True][1][k]
+        scale = max(v.double().abs().max().item(), 1e-3)
+        assert (v.double() - w.double()).abs().max().item() <= 2e-3 * scale, k
+    se, sg_ = runs[False][2].optimizer.state_dict()["state"], runs[True][2].optimizer.state_dict()["state"]
+    assert se.keys() == sg_.keys()
+    for k in se:
+        assert int(se[k]["step"]) == int(sg_[k]["step"]) == 7
+
+
+def test_replays_draw_new_masks_and_follow_the_learning_rate():
+    sg = _graph()
+    m, learner = _learner(False, True)
+    metrics, logs, labels = _data(0)
+    for _ in range(3):
+        learner.process_tensors(metrics, sg, logs, labels)
+    assert len(learner._graphed) == 1
+    # learning rate 0 (and no weight decay effect through lr): parameters freeze, yet the loss of identical inputs
+    # still changes from replay to replay because every replay draws new dropout masks
+    for group in learner.optimizer.param_groups:
+        group["lr"] = 0.0
+    learner.lr_scheduler.current_lr = 0.0
+    learner.lr_scheduler.min_lr = 0.0
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    losses = [learner.process_tensors(metrics, sg, logs, labels)["batch_loss"] for _ in range(4)]
+    assert len(set(round(x, 7) for x in losses)) > 1, losses
+    for k, v in m.named_parameters():
+        assert torch.equal(v, before[k]), k
+    # and back on: parameters move again
+    for group in learner.optimizer.param_groups:
+        group["lr"] = 1e-3
+    learner.lr_scheduler.current_lr = 1e-3
+    learner.process_tensors(metrics, sg, logs, labels)
+    assert any(not torch.equal(v, before[k]) for k, v in m.named_parameters())
+
+
+def test_bank_mode_and_new_shapes_fall_back_to_eager():
+    sg = _graph()
+    m, learner = _learner(True, True, negatives="bank")
+    metrics, logs, labels = _data(0, B=2)
+    for _ in range(4):
+        learner.process_tensors(metrics, sg, logs, labels)
+    assert len(learner._graphed) == 0          # the ring pointer of the memory bank is host state: not recorded
+    m, learner = _learner(True, True)
+    for i in range(4):
+        learner.process_tensors(*(lambda d: (d[0], sg, d[1], d[2]))(_data(i, B=3 + i)))   # a new batch size every step
+    assert len(learner._graphed) == 0 and learner.update_count == 4
