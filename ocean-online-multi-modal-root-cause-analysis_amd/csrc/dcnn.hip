@@ -304,16 +304,6 @@ __global__ void bn_bwd_param_kernel(const double* __restrict__ bslots, double* _
   if (dgamma) dgamma[c] += (float)sx;
 }
 
-__global__ void mean_t_kernel(const float* __restrict__ a, float* __restrict__ out, int T, int C) {
-  const int b = blockIdx.x;
-  const int c = blockIdx.y * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float* p = a + (long)b * T * C + c;
-  float s = 0.f;
-  for (int t = 0; t < T; ++t) s += p[(long)t * C];
-  out[(long)b * C + c] = s / (float)T;
-}
-
 // [Co][Ci][Kt] -> [Kt][Co][Ci]
 __global__ void repack_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int Kt) {
   const long n = (long)Co * Ci * Kt;
@@ -460,8 +450,7 @@ int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* para
         OCEAN_TRY(conv_fwd(pl, s, j + 1, ws + pl.a[j], params, ws, st));
       } else {
         const int C = s->channels[L - 1];
-        hipLaunchKernelGGL(mean_t_kernel, dim3(s->B, ceil_div(C, 256)), dim3(256), 0, st, ws + pl.a[j], ws + pl.pooled, s->T, C);
-        OCEAN_LAUNCH_CHECK();
+        OCEAN_TRY(mean_mid(ws + pl.a[j], ws + pl.pooled, s->B, s->T, C, st));
         OCEAN_TRY(linear_fwd(ws + pl.pooled, C, params[pi_out(L, 0)], params[pi_out(L, 1)], out, s->out_dim, s->B, s->out_dim, C, 0, st));
       }
     }

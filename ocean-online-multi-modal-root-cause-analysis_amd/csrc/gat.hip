@@ -79,6 +79,36 @@ __device__ __forceinline__ void head_sums(const float (&prod)[CPL], float (&hs)[
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : slope * x; }
 
+// Cross-lane reductions on the VALU data-parallel-primitive path.  __shfl_xor goes through the LDS crossbar
+// (ds_bpermute), and at ~50 shuffles per node the gather kernels were bound by that pipe; within a row of 16 lanes
+// the same sums are available as DPP modifiers on ordinary VALU instructions.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;   // quad_perm / row mirrors
+// sum over aligned groups of `width` consecutive lanes (power of two); every lane of the group gets the total
+__device__ __forceinline__ float group_sum(float v, int width) {
+  if (width >= 2) v += dpp_f<kDppXor1>(v);
+  if (width >= 4) v += dpp_f<kDppXor2>(v);
+  if (width >= 8) v += dpp_f<kDppHalfMirror>(v);     // lane i <- lane 7-i of its half row: the other quad's total
+  if (width >= 16) v += dpp_f<kDppMirror>(v);        // lane i <- lane 15-i: the other half row's total
+  for (int o = 16; o < width; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// reductions over the lanes that share (lane % stride), stride a power of two: row rotations inside a 16-lane
+// row, LDS-crossbar shuffles across rows
+template <bool MAX>
+__device__ __forceinline__ float strided_reduce(float v, int stride) {
+  auto comb = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  if (stride <= 1) v = comb(v, dpp_f<0x121>(v));     // row_ror:1
+  if (stride <= 2) v = comb(v, dpp_f<0x122>(v));     // row_ror:2
+  if (stride <= 4) v = comb(v, dpp_f<0x124>(v));     // row_ror:4
+  if (stride <= 8) v = comb(v, dpp_f<0x128>(v));     // row_ror:8
+  for (int o = stride > 16 ? stride : 16; o < 64; o <<= 1) v = comb(v, __shfl_xor(v, o));
+  return v;
+}
+
 // a_s[row,h] = sum_c Z[row,h,c]*att_src[h,c]; same for a_d
 template <int CPL, bool FAST>
 __global__ __launch_bounds__(256) void gat_scores_kernel(GatK g, const float* __restrict__ Z, const float* __restrict__ att_src,
@@ -218,7 +248,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_fast_kernel(GatK g, int hlo
     mx = fmaxf(mx, sv);
     s_last = sv; j_last = j;
   }
-  for (int o = H; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  mx = strided_reduce<true>(mx, H);
   float den = 0.f, acc[CPL];
 #pragma unroll
   for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
@@ -253,7 +283,7 @@ __global__ __launch_bounds__(256) void gat_aggregate_fast_kernel(GatK g, int hlo
         for (int k = 0; k < CPL; ++k) acc[k] = fmaf(ww[u], zz[u][k], acc[k]);
     }
   }
-  for (int o = H; o < 64; o <<= 1) den += __shfl_xor(den, o);
+  den = strided_reduce<false>(den, H);
   wave_lds_sync();
   if (le == 0) { smax[node * H + lh] = mx; sden[node * H + lh] = den; dl[lh] = den; }
   wave_lds_sync();
@@ -263,13 +293,28 @@ __global__ __launch_bounds__(256) void gat_aggregate_fast_kernel(GatK g, int hlo
   store_row<CPL>(agg + node * g.HC + c0, acc);
 }
 
+// da_d[row, h] = sum over the incoming edges e of row's node of ds_edge[(r*E + e), h]   (edges of one target are
+// consecutive in by-target order, so each thread reads a short contiguous run)
+__global__ void gat_bwd_target_sum_kernel(GatK g, const float* __restrict__ ds_edge, float* __restrict__ da_d) {
+  const long n = (long)g.R * g.N * g.H;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+    const int h = (int)(t % g.H);
+    const long row = t / g.H;
+    const int i = (int)(row % g.N);
+    const long r = row / g.N;
+    float s = 0.f;
+    for (int e = g.rp_in[i]; e < g.rp_in[i + 1]; ++e) s += ds_edge[(r * g.E + e) * g.H + h];
+    da_d[t] = s;
+  }
+}
+
 template <int CPL>
 __global__ __launch_bounds__(256) void gat_bwd_source_fast_kernel(GatK g, int hlog, const float* __restrict__ Z,
                                                                   const float* __restrict__ a_s, const float* __restrict__ a_d,
                                                                   const float* __restrict__ smax, const float* __restrict__ sden,
                                                                   const float* __restrict__ dagg, const float* __restrict__ Dn,
                                                                   float* __restrict__ dZ, float* __restrict__ da_s,
-                                                                  float* __restrict__ da_d) {
+                                                                  float* __restrict__ ds_edge) {
   g.att_drop = dropout_resolve(g.att_drop);
   __shared__ float wl_all[kWavesPerBlock][64];
   __shared__ float hl_all[kWavesPerBlock][64];
@@ -298,8 +343,9 @@ __global__ __launch_bounds__(256) void gat_bwd_source_fast_kernel(GatK g, int hl
     const long nh = (rbase + i) * H + lh;
     const float raw = asl + a_d[(zbase + i) * H + lh];
     const float alpha = valid ? __expf(lrelu(raw, g.slope) - smax[nh]) / (sden[nh] + 1e-16f) : 0.f;
+    const long eslot = valid ? ((long)r * g.E + g.eid_out[e]) * H + lh : 0;   // this edge's slot in by-target order
     float keep = 1.f;
-    if (g.att_drop.p > 0.f && valid) keep = dropout_keep(g.att_drop, ((uint64_t)r * g.E + g.eid_out[e]) * H + lh);
+    if (g.att_drop.p > 0.f && valid) keep = dropout_keep(g.att_drop, (uint64_t)eslot);
     const float dnv = Dn[nh];
     wave_lds_sync();
     wl[lane] = alpha * keep;
@@ -320,10 +366,8 @@ __global__ __launch_bounds__(256) void gat_bwd_source_fast_kernel(GatK g, int hl
         for (int k = 0; k < CPL; ++k) { dz[k] = fmaf(ww[u], dg[u][k], dz[k]); p = fmaf(dg[u][k], z[k], p); }
         pr[u] = p;
       }
-      for (int o = LPH >> 1; o > 0; o >>= 1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pr[u] += __shfl_xor(pr[u], o);
-      }
+      for (int u = 0; u < 4; ++u) pr[u] = group_sum(pr[u], LPH);
       if ((lane & (LPH - 1)) == 0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) hl[((q + u) << hlog) + hk] = pr[u];
@@ -334,10 +378,10 @@ __global__ __launch_bounds__(256) void gat_bwd_source_fast_kernel(GatK g, int hl
       const float de = alpha * (keep * hl[lane] - dnv);
       const float ds = de * (raw > 0.f ? 1.f : g.slope);
       das += ds;
-      unsafeAtomicAdd(da_d + nh, ds);
+      ds_edge[eslot] = ds;     // summed per target by gat_bwd_target_sum_kernel: a plain store instead of an atomic
     }
   }
-  for (int o = H; o < 64; o <<= 1) das += __shfl_xor(das, o);
+  das = strided_reduce<false>(das, H);
   if (le == 0) da_s[node * H + lh] = das;
   store_row<CPL>(dZ + node * g.HC + c0, dz);
 }
@@ -401,9 +445,7 @@ __global__ __launch_bounds__(256) void gat_scores_fast_kernel(GatK g, int hlog, 
       s0 = fmaf(z0[k], as_[k], s0); d0 = fmaf(z0[k], ad_[k], d0);
       s1 = fmaf(z1[k], as_[k], s1); d1 = fmaf(z1[k], ad_[k], d1);
     }
-    for (int o = LPH >> 1; o > 0; o >>= 1) {
-      s0 += __shfl_xor(s0, o); d0 += __shfl_xor(d0, o); s1 += __shfl_xor(s1, o); d1 += __shfl_xor(d1, o);
-    }
+    s0 = group_sum(s0, LPH); d0 = group_sum(d0, LPH); s1 = group_sum(s1, LPH); d1 = group_sum(d1, LPH);
     if ((lane & (LPH - 1)) == 0) {
       a_s[node * g.H + hk] = s0; a_d[node * g.H + hk] = d0;
       if (two) { a_s[n2 * g.H + hk] = s1; a_d[n2 * g.H + hk] = d1; }
@@ -457,7 +499,7 @@ __global__ __launch_bounds__(256) void gat_bwd_prep_fast_kernel(GatK g, int hlog
       dn = fmaf(da[k], a[k], dn);
     }
     store_row<CPL>(dagg + node * g.HC + c0, da);
-    for (int o = LPH >> 1; o > 0; o >>= 1) dn += __shfl_xor(dn, o);
+    dn = group_sum(dn, LPH);
     if ((lane & (LPH - 1)) == 0) Dn[node * H + hk] = dn;
   }
   block_channel_sums<CPL>(gb, bias_slots, od, oc0, concat || hk == 0, red);
@@ -676,17 +718,6 @@ __global__ void sum_replicas_kernel(const float* __restrict__ src, float* __rest
   for (; r < r1; ++r) s0 += src[(long)r * per + i];
   unsafeAtomicAdd(dst + i, (s0 + s1) + (s2 + s3));
 }
-// [G, n, C] -> [G, C] mean over the middle axis
-__global__ void mean_mid_kernel(const float* __restrict__ a, float* __restrict__ out, int n, int C) {
-  const int b = blockIdx.x;
-  const int c = blockIdx.y * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float* p = a + (long)b * n * C + c;
-  float s = 0.f;
-  for (int t = 0; t < n; ++t) s += p[(long)t * C];
-  out[(long)b * C + c] = s / (float)n;
-}
-
 inline int egrid(long n) {
   long g = (n + 255) / 256;
   if (g > 8192) g = 8192;
@@ -701,7 +732,7 @@ struct GnnPlan {
   long rows;                       // R*N
   int in_dim[8], out_dim[8], concat[8], residual[8];
   size_t x0, xb, Z[8], as_[8], ad[8], smax[8], sden[8], agg[8], y[8], pooled, fwd_total;
-  size_t dY, dZ, dagg, Dn, das, dad, dpool, dx0, slots, bwd_total;
+  size_t dY, dZ, dagg, Dn, das, dad, dse, dpool, dx0, slots, bwd_total;
 };
 
 inline size_t al4(size_t x) { return (x + 3) & ~size_t(3); }
@@ -738,6 +769,7 @@ int make_plan(const ocean_gnn_shape* s, GnnPlan* p) {
   o = 0;
   p->dY = take(rows * s->D); p->dZ = take(rows * s->D); p->dagg = take(rows * s->D);
   p->Dn = take(rows * s->H); p->das = take(rows * s->H); p->dad = take(rows * s->H);
+  p->dse = take((size_t)s->R * s->E * s->H);    // per-edge score gradients (fast path)
   p->dpool = take((size_t)p->P * p->out_dim[s->layers - 1]);
   p->dx0 = take((size_t)s->N * s->D);
   p->slots = take((size_t)3 * kSumSlots * s->D);   // bias, att_src, att_dst partial sums
@@ -885,8 +917,7 @@ int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features, const in
     xin = ws + pl.y[l];
   }
   const int Cl = pl.out_dim[pl.layers - 1];
-  hipLaunchKernelGGL(mean_mid_kernel, dim3(pl.P, ceil_div(Cl, 64)), dim3(64), 0, st, xin, ws + pl.pooled, pl.pool_n, Cl);
-  OCEAN_LAUNCH_CHECK();
+  OCEAN_TRY(mean_mid(xin, ws + pl.pooled, pl.P, pl.pool_n, Cl, st));
   OCEAN_TRY(linear_fwd(ws + pl.pooled, Cl, params[pg_out(pl.layers, 0)], params[pg_out(pl.layers, 1)], out, D, pl.P, D, Cl, 0, st));
   return OCEAN_OK;
 }
@@ -935,13 +966,16 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
       else for (int h = 0; h < H; ++h) OCEAN_TRY(colsum_add(wb + pl.dagg + h * C, D, (int)rows, C, grads[pg_layer(l, 3)], st));
       GAT_DISPATCH(gat_bwd_dot_kernel, g, wb + pl.dagg, wf + pl.agg[l], wb + pl.Dn);
     }
-    OCEAN_TRY(zero_f32(wb + pl.dad, rows * H, st));
-    if (fast_edges(pl))
+    if (fast_edges(pl)) {
       GAT_DISPATCH_FAST(gat_bwd_source_fast_kernel, wf + pl.Z[l], wf + pl.as_[l], wf + pl.ad[l], wf + pl.smax[l], wf + pl.sden[l],
-                        wb + pl.dagg, wb + pl.Dn, wb + pl.dZ, wb + pl.das, wb + pl.dad);
-    else
+                        wb + pl.dagg, wb + pl.Dn, wb + pl.dZ, wb + pl.das, wb + pl.dse);
+      hipLaunchKernelGGL(gat_bwd_target_sum_kernel, dim3(egrid(rows * H)), dim3(256), 0, st, g, wb + pl.dse, wb + pl.dad);
+      OCEAN_LAUNCH_CHECK();
+    } else {
+      OCEAN_TRY(zero_f32(wb + pl.dad, rows * H, st));
       GAT_DISPATCH(gat_bwd_source_kernel, g, wf + pl.Z[l], wf + pl.as_[l], wf + pl.ad[l], wf + pl.smax[l], wf + pl.sden[l],
                    wb + pl.dagg, wb + pl.Dn, wb + pl.dZ, wb + pl.das, wb + pl.dad);
+    }
     if (fast) {
       GAT_STREAM_FAST(gat_bwd_att_fast_kernel, wf + pl.Z[l], wb + pl.dZ, wb + pl.das, wb + pl.dad, params[pg_layer(l, 1)],
                       params[pg_layer(l, 2)], slot_s, slot_d);

@@ -146,14 +146,40 @@ __global__ void dropout_kernel(float* __restrict__ x, int ld, int M, int N, int 
   }
 }
 
-__global__ void mean_mid_kernel2(const float* __restrict__ a, float* __restrict__ out, int n, int C) {
-  const int b = blockIdx.x;
-  const int c = blockIdx.y * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float* p = a + (long)b * n * C + c;
-  float s = 0.f;
-  for (int t = 0; t < n; ++t) s += p[(long)t * C];
-  out[(long)b * C + c] = s / (float)n;
+// out[g, c] = mean over t of a[g, t, c].  Block = W column groups (VEC columns each) x 256/W row lanes; the row
+// lanes split the middle axis and are combined through LDS.
+template <int VEC>
+__global__ __launch_bounds__(256) void mean_mid_kernel2(const float* __restrict__ a, float* __restrict__ out, int n, int C, int wlog) {
+  __shared__ float red[256 * VEC];
+  const int W = 1 << wlog, RL = 256 >> wlog;
+  const int tx = threadIdx.x & (W - 1), ty = threadIdx.x >> wlog;
+  const int c0 = (blockIdx.y * W + tx) * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  if (c0 < C) {
+    const float* p = a + (long)blockIdx.x * n * C + c0;
+#pragma unroll 4
+    for (int t = ty; t < n; t += RL) {
+      if (VEC == 4) {
+        const float4 x = *reinterpret_cast<const float4*>(p + (long)t * C);
+        acc[0] += x.x; acc[1 % VEC] += x.y; acc[2 % VEC] += x.z; acc[3 % VEC] += x.w;
+      } else {
+        acc[0] += p[(long)t * C];
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) red[threadIdx.x * VEC + v] = acc[v];
+  __syncthreads();
+  if (ty == 0 && c0 < C) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float s = 0.f;
+      for (int q = 0; q < RL; ++q) s += red[(q * W + tx) * VEC + v];
+      out[(long)blockIdx.x * C + c0 + v] = s / (float)n;
+    }
+  }
 }
 
 }  // namespace
@@ -214,7 +240,13 @@ int dropout_inplace(float* x, int ld, int M, int N, int group, DropoutP d, hipSt
 }
 
 int mean_mid(const float* a, float* out, int G, int n, int C, hipStream_t s) {
-  hipLaunchKernelGGL(mean_mid_kernel2, dim3(G, ceil_div(C, 64)), dim3(64), 0, s, a, out, n, C);
+  const bool v4 = C % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0;
+  const int cg = v4 ? C / 4 : C;
+  int wlog = 0;
+  while ((1 << wlog) < cg && wlog < 8) ++wlog;
+  const dim3 grid(G, ceil_div(cg, 1 << wlog));
+  if (v4) hipLaunchKernelGGL(mean_mid_kernel2<4>, grid, dim3(256), 0, s, a, out, n, C, wlog);
+  else hipLaunchKernelGGL(mean_mid_kernel2<1>, grid, dim3(256), 0, s, a, out, n, C, wlog);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }

@@ -67,10 +67,11 @@ def c1():
             "p50": ts[len(ts) // 2] * 1e3, "p99": ts[int(len(ts) * 0.99)] * 1e3}
 
 
-def train_cfg(name, N, S, deg, B, T, steps):
+def train_cfg(name, N, S, deg, B, T, steps, use_graph=True):
     cfg, m, graph = make(N, S, deg)
     m.contrastive_negatives = "in_batch"
     learner = OnlineLearner(m, cfg)
+    learner.use_hip_graph = use_graph
     metrics, logs, labels = inputs(B, T, S)
     for _ in range(3):
         learner.process_tensors(metrics, graph, logs, labels)
@@ -81,27 +82,31 @@ def train_cfg(name, N, S, deg, B, T, steps):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"config": name, "metric": "samples/sec fwd+bwd online step", "unit": "samples/s", "value": B / dt, "ms_per_step": dt * 1e3,
-            "batch": B, "seq_len": T, "services": N}
+            "batch": B, "seq_len": T, "services": N, "launch": "hip-graph replay" if learner._graphed else "eager"}
 
 
-def c5():
+def c5(use_graph=True):
     cfg, m, graph = make(64, 64, 4.0)
+    m.contrastive_negatives = "in_batch"
     learner = OnlineLearner(m, cfg)
+    learner.use_hip_graph = use_graph
     metrics, logs, labels = inputs(8, 64, 64)
     ts = sorted(timed(lambda: learner.process_tensors(metrics, graph, logs, labels), 10, 200))
     return {"config": "C5 per-window online update (64 services, seq_len 64, window batch 8, one stream group on one GPU)",
             "metric": "update latency", "unit": "ms", "p50": ts[len(ts) // 2] * 1e3, "p99": ts[int(len(ts) * 0.99)] * 1e3,
-            "samples_per_s": 8 / (sum(ts) / len(ts))}
+            "samples_per_s": 8 / (sum(ts) / len(ts)), "launch": "hip-graph replay" if learner._graphed else "eager"}
 
 
 which = sys.argv[1:] or ["C1", "C2", "C4", "C5"]
 for w in which:
-    if w == "C1":
-        r = c1()
-    elif w == "C2":
-        r = train_cfg("C2 online step (64 services, batch 256, seq_len 64, in-batch InfoNCE)", 64, 64, 4.0, 256, 64, 20)
-    elif w == "C4":
-        r = train_cfg("C4 one GPU's share (4096 services, in-degree 8, batch 64 of 512, seq_len 128, in-batch InfoNCE)", 4096, 4096, 8.0, 64, 128, 10)
-    else:
-        r = c5()
-    print(json.dumps(r), flush=True)
+    for use_graph in ((True,) if w == "C1" else (False, True)):
+        if w == "C1":
+            r = c1()
+        elif w == "C2":
+            r = train_cfg("C2 online step (64 services, batch 256, seq_len 64, in-batch InfoNCE)", 64, 64, 4.0, 256, 64, 20, use_graph)
+        elif w == "C4":
+            r = train_cfg("C4 one GPU's share (4096 services, in-degree 8, batch 64 of 512, seq_len 128, in-batch InfoNCE)", 4096, 4096,
+                          8.0, 64, 128, 10, use_graph)
+        else:
+            r = c5(use_graph)
+        print(json.dumps(r), flush=True)
