@@ -58,16 +58,31 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_kernel(const GemmBatch batc
   const int tiles_m = (p.M + BM - 1) / BM;
   const int nwg = tiles_m * tiles_n;
   if ((int)blockIdx.x >= nwg) return;          // the grid is sized for the largest problem of the batch
-  const int bid = xcd_swizzle(blockIdx.x, nwg);
+  int bid = xcd_swizzle(blockIdx.x, nwg);
+  int ztap = 0, zs = 0;
+  if (AKM) {
+    const int split = p.split_k > 0 ? p.split_k : 1;
+    ztap = blockIdx.z / split;
+    zs = blockIdx.z % split;
+    if (gridDim.y == 1) {
+      // Row reductions: every block of one reduction chunk (all output tiles, all taps) reads the same rows of
+      // A and B, so chunks - not tiles - are what an XCD's L2 should share.  Blocks are dealt to XCDs round-robin
+      // in linear-id order; give each XCD a contiguous run of (chunk, tap, tile) triples.
+      const int total = nwg * (int)gridDim.z;
+      const int q = xcd_swizzle((int)(blockIdx.x + gridDim.x * blockIdx.z), total);
+      const int per_chunk = nwg * p.taps;
+      zs = q / per_chunk;
+      ztap = (q % per_chunk) / nwg;
+      bid = q % nwg;
+    }
+  }
   const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // reduction range / tap handled by this block
-  int k_begin = 0, k_end = p.K, ztap = 0;
+  int k_begin = 0, k_end = p.K;
   if (AKM) {
     const int split = p.split_k > 0 ? p.split_k : 1;
-    ztap = blockIdx.z / split;
-    const int zs = blockIdx.z % split;
     int chunk = (p.K + split - 1) / split;
     chunk = (chunk + BK - 1) / BK * BK;
     k_begin = zs * chunk;
