@@ -24,6 +24,7 @@ from ... import _hip
 from ...configs import OCEANConfig
 from ...data.data_types import DatasetSample
 from ...optim import FusedAdam
+from ...staging import BatchStager
 from ..ocean_model import OCEANModel
 
 logger = logging.getLogger(__name__)
@@ -175,6 +176,7 @@ class _GraphedStep:
         self.graph.replay()
         learner.optimizer.after_replay()
         learner.update_count += 1
+        learner._before_readback()
         return dict(zip(self.keys, self.loss_vec.cpu().tolist()))
 
 
@@ -199,6 +201,12 @@ class OnlineLearner:
         # step as a HIP graph and replays it from then on (single-GPU, FusedAdam, in-batch contrastive mode)
         self.use_hip_graph = False
         self._graphed: Dict[Any, _GraphedStep] = {}
+        # pinned_staging: process_batch collates host samples through page-locked buffers and reused device
+        # tensors (ocean/staging.py) instead of three pageable torch.stack results; same values either way
+        self.pinned_staging = True
+        self._stager: Optional[BatchStager] = None
+        self._prefetch_next: Optional[List[DatasetSample]] = None
+        self._prefetched = None
         self._graph_seen: Dict[Any, int] = defaultdict(int)
 
     # ------------------------------------------------------------------ the update step
@@ -246,15 +254,48 @@ class OnlineLearner:
             results["contrastive_loss"] = host["contrastive_loss"]
         return results
 
-    def process_batch(self, batch_samples: List[DatasetSample]) -> Dict[str, float]:
+    def process_batch(self, batch_samples: List[DatasetSample], prefetch: Optional[List[DatasetSample]] = None) -> Dict[str, float]:
+        """One update from a list of samples (online_learner.py:362-431).  `prefetch` (not in the reference) names the
+        list the caller will pass next: it is collated and copied to the device while the GPU works on this
+        update, and a following process_batch(prefetch) call with that same list object starts on staged data."""
         if not batch_samples:
             return {}
         self.model.train()
         service_graph = batch_samples[0].graph          # one graph for the batch (online_learner.py:382-383)
+        staged = self._take_staged(batch_samples)
+        if staged is not None:
+            self._prefetch_next = prefetch
+            try:
+                self._stager.acquire(staged)
+                return self.process_tensors(staged[0], service_graph, staged[1], staged[2])
+            finally:
+                self._prefetch_next = None
+                self._stager.release(staged)
         metrics = torch.stack([s.metrics for s in batch_samples])
         logs = torch.stack([s.logs for s in batch_samples])
         labels = torch.stack([s.label for s in batch_samples])
         return self.process_tensors(metrics, service_graph, logs, labels)
+
+    def _take_staged(self, batch_samples):
+        """Device tensors of this batch out of the pinned staging ring: the ones a previous call prefetched for
+        this very list, or a fresh collate; None when staging does not apply."""
+        held, self._prefetched = self._prefetched, None
+        if held is not None and held[0] is batch_samples and len(batch_samples) == held[1]:
+            return held[2]
+        if not (self.pinned_staging and self.model.device.type == "cuda" and BatchStager.stageable(batch_samples)):
+            return None
+        if self._stager is None or self._stager.device != self.model.device:
+            self._stager = BatchStager(self.model.device)
+        return self._stager.collate(batch_samples)
+
+    def _before_readback(self) -> None:
+        """Called once per update after its last kernel is queued and before the host blocks on the loss values:
+        the host is idle from here to the end of the GPU work, so the next batch is collated now."""
+        nxt, self._prefetch_next = self._prefetch_next, None
+        if nxt and self._stager is not None and BatchStager.stageable(nxt):
+            staged = self._stager.collate(nxt)
+            if staged is not None:
+                self._prefetched = (nxt, len(nxt), staged)
 
     def process_tensors(self, metrics: torch.Tensor, service_graph, logs: torch.Tensor, labels: torch.Tensor) -> Dict[str, float]:
         """process_batch on already-collated tensors ([B,T,F], graph, [B,768], [B,S]); tensors that
@@ -265,6 +306,7 @@ class OnlineLearner:
             outputs = self.model(metrics, service_graph, logs)
             losses = self.model.compute_loss(outputs, labels.to(self.model.device, non_blocking=True))
             self._apply_update(losses["total_loss"])
+            self._before_readback()
             host = self._losses_to_host(losses)
         current_lr = self.lr_scheduler.step(host["total_loss"], self.optimizer)
         self.performance_history["batch_loss"].append(host["total_loss"])

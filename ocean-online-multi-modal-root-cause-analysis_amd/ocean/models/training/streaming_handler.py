@@ -207,10 +207,15 @@ class StreamProcessor:
 
     def _process_samples(self, samples: List[DatasetSample]) -> int:
         done = 0
-        for i in range(0, len(samples), self.batch_size):
-            batch = samples[i:i + self.batch_size]
+        batches = [samples[i:i + self.batch_size] for i in range(0, len(samples), self.batch_size)]
+        stages = getattr(self.online_learner, "pinned_staging", False)   # a learner with the reference's signature: no hint
+        for k, batch in enumerate(batches):
             try:
-                self.online_learner.process_batch(batch)
+                if stages and k + 1 < len(batches):
+                    # the following batch is staged on the device while this update runs
+                    self.online_learner.process_batch(batch, prefetch=batches[k + 1])
+                else:
+                    self.online_learner.process_batch(batch)
                 done += len(batch)
             except Exception as e:          # the reference logs and moves on (streaming_handler.py:355-356)
                 logger.error("Error processing batch: %s", e)

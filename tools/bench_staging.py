@@ -1,0 +1,70 @@
+"""Host-inclusive cost of one online update: OnlineLearner.process_batch on a list of host-resident DatasetSample
+(the form the stream front-end delivers), with the pinned staging ring on and off, next to process_tensors on
+HBM-resident tensors.  One JSON line per case.
+
+    python tools/bench_staging.py
+"""
+import json
+import os
+import sys
+import time
+from datetime import datetime
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ocean-online-multi-modal-root-cause-analysis_amd"))
+import torch  # noqa: E402
+import ocean  # noqa: E402
+from ocean.data import DatasetSample, ServiceGraph  # noqa: E402
+from ocean.models.training import OnlineLearner  # noqa: E402
+
+dev = torch.device("cuda", 0)
+g = lambda s: torch.Generator().manual_seed(s)
+
+
+def case(name, N, deg, B, T, steps):
+    cfg = ocean.default_config()
+    cfg.model.num_services = N
+    nf = torch.randn(N, 12, generator=g(7))
+    adj = (torch.rand(N, N, generator=g(11)) < deg / N).float()
+    adj.fill_diagonal_(0.0)
+    graph = ServiceGraph(adjacency_matrix=adj, node_features=nf)
+    metrics, logs = torch.randn(B, T, 12, generator=g(1000)), torch.randn(B, 768, generator=g(2000))
+    labels = torch.zeros(B, N)
+    labels[torch.arange(B), torch.randint(0, N, (B,), generator=g(3000))] = 1.0
+    samples = [DatasetSample(metrics=metrics[i].clone(), logs=logs[i].clone(), graph=graph, label=labels[i].clone(),
+                             timestamp=datetime.now()) for i in range(B)]
+    dm, dl, dy = metrics.to(dev), logs.to(dev), labels.to(dev)
+    other = list(reversed(samples))
+    turn = [0]
+    for mode in ("resident tensors", "host samples, stacked (reference collate)", "host samples, pinned staging ring",
+                 "host samples, pinned staging ring, next batch prefetched"):
+        torch.manual_seed(42)
+        m = ocean.OCEANModel(cfg).to(dev)
+        m.contrastive_negatives = "in_batch"
+        learner = OnlineLearner(m, cfg)
+        learner.use_hip_graph = True
+        learner.pinned_staging = "ring" in mode
+
+        def alternate():            # two sample lists in turn, each call naming the other as its successor
+            cur, nxt = (samples, other) if turn[0] % 2 == 0 else (other, samples)
+            turn[0] += 1
+            learner.process_batch(cur, prefetch=nxt)
+
+        fn = ((lambda: learner.process_tensors(dm, graph, dl, dy)) if mode.startswith("resident") else alternate if "prefetched" in mode
+              else (lambda: learner.process_batch(samples)))
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        print(json.dumps({"config": name, "input": mode, "ms_p50": ts[len(ts) // 2] * 1e3, "ms_mean": sum(ts) / len(ts) * 1e3,
+                          "samples_per_s": B / (sum(ts) / len(ts)), "batch": B, "bytes_staged": B * (T * 48 + 3072 + 4 * N)}), flush=True)
+
+
+case("C3 (256 services, batch 1024, seq_len 128)", 256, 8.0, 1024, 128, 20)
+case("C5 window (64 services, batch 8, seq_len 64)", 64, 4.0, 8, 64, 200)
