@@ -46,6 +46,15 @@ struct Lane {
   }
 };
 
+// Orders one wave's LDS traffic: lanes exchange values through wave-private LDS, and the LDS unit serves one wave's
+// instructions in program order, so only the compiler has to be kept from moving accesses across this point.  (A
+// workgroup-scope fence here also waits for every outstanding global load and store of the wave, which made each
+// node wait for the previous node's output stores to be acknowledged.)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // hs[k] = sum over the head of channel (c0+k) of prod[.]
 template <int CPL, bool FAST>
 __device__ __forceinline__ void head_sums(const float (&prod)[CPL], float (&hs)[CPL], const Lane<CPL>& L, const GatK& g,
@@ -59,19 +68,16 @@ __device__ __forceinline__ void head_sums(const float (&prod)[CPL], float (&hs)[
     for (int k = 0; k < CPL; ++k) hs[k] = v;
   } else {
     // wave-private LDS: [HC] products then [H] sums
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < CPL; ++k) if (L.ok[k]) wlds[L.c0 + k] = prod[k];
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
     for (int h = lane; h < g.H; h += 64) {
       float s = 0.f;
       for (int c = 0; c < g.C; ++c) s += wlds[h * g.C + c];
       wlds[g.HC + h] = s;
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < CPL; ++k) hs[k] = L.ok[k] ? wlds[g.HC + L.hk[k]] : 0.f;
   }
@@ -211,10 +217,6 @@ __device__ __forceinline__ void store_row(float* p, const float (&v)[CPL]) {
     for (int q = 0; q < CPL / 4; ++q)
       reinterpret_cast<float4*>(p)[q] = make_float4(v[(4 * q) % CPL], v[(4 * q + 1) % CPL], v[(4 * q + 2) % CPL], v[(4 * q + 3) % CPL]);
   }
-}
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  __builtin_amdgcn_wave_barrier();
 }
 
 template <int CPL>
@@ -384,6 +386,301 @@ __global__ __launch_bounds__(256) void gat_bwd_source_fast_kernel(GatK g, int hl
   das = strided_reduce<false>(das, H);
   if (le == 0) da_s[node * H + lh] = das;
   store_row<CPL>(dZ + node * g.HC + c0, dz);
+}
+
+// ---- replica-block variants for small graphs ------------------------------------------------------------------
+// Counters on the one-node-per-wave kernels above show the vector ALU as their limit (about 250 vector instructions
+// per node, most of them address arithmetic and table lookups that are the same for all 64 lanes).  Here a block
+// takes a whole replica (or a node range of it): the per-(node, head) tables the edge lanes index are staged in LDS
+// once per block, the node index is wave-uniform so the CSR walk and the row addresses of the gathers are scalar
+// loads and scalar arithmetic, and the head count is a template parameter so LDS offsets fold into the instructions.
+constexpr int kTileWaves = 16;
+constexpr int kWaitVm0 = 0x0F70;   // s_waitcnt vmcnt(0) only (expcnt, lgkmcnt fields at their maxima)
+
+// a * b + c on the full-rate 24-bit multiplier (a, b < 2^24); the 32-bit integer multiply runs at a quarter of that
+__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+
+// CPL consecutive floats at byte offset `off` of a bounds-checked buffer (reads past the end return 0)
+template <int CPL>
+__device__ __forceinline__ void load_row_buf(__amdgpu_buffer_rsrc_t rs, unsigned off, float (&v)[CPL]) {
+  // (a bit_cast applied to a vector element reads element 0: copy the elements out first)
+  if constexpr (CPL == 1) {
+    v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+  } else if constexpr (CPL == 2) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+    const unsigned x = r[0], y = r[1];
+    v[0] = __uint_as_float(x); v[1] = __uint_as_float(y);
+  } else {
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q) {
+      const auto r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off + 16 * q, 0, 0);
+      const unsigned x = r[0], y = r[1], z = r[2], w = r[3];
+      v[4 * q] = __uint_as_float(x); v[4 * q + 1] = __uint_as_float(y); v[4 * q + 2] = __uint_as_float(z); v[4 * q + 3] = __uint_as_float(w);
+    }
+  }
+}
+
+template <int CPL, int HLOG>
+__global__ __launch_bounds__(kTileWaves * 64) void gat_aggregate_tile_kernel(GatK g, int npb, const float* __restrict__ Z,
+                                                                             const float* __restrict__ a_s,
+                                                                             const float* __restrict__ a_d, float* __restrict__ agg,
+                                                                             float* __restrict__ smax, float* __restrict__ sden) {
+  constexpr int H = 1 << HLOG, EPW = 64 >> HLOG;
+  constexpr int RB = CPL <= 2 ? 8 : 4, GB = EPW < RB ? EPW : RB;   // rows in flight per wave
+  g.att_drop = dropout_resolve(g.att_drop);
+  extern __shared__ float lds[];
+  const int N = g.N, E = g.E;
+  float* as_l = lds;                                         // [N*H]   source logits of this replica
+  float* ad_l = as_l + N * H;                                // [N*H]   target logits
+  int* src_l = reinterpret_cast<int*>(ad_l + N * H);         // [E+GB]  padded: the early row requests read GB indices
+  float* wsc = reinterpret_cast<float*>(src_l + E + GB);      // per wave: weights [64], row indices [64], denominators [16]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = blockIdx.x;
+  const long rbase = (long)r * N;
+  const long zbase = g.z_shared ? 0 : rbase;
+  for (int t = threadIdx.x; t < N * H; t += kTileWaves * 64) { as_l[t] = a_s[zbase * H + t]; ad_l[t] = a_d[zbase * H + t]; }
+  for (int t = threadIdx.x; t < E + GB; t += kTileWaves * 64) src_l[t] = t < E ? g.src_in[t] : 0;
+  __syncthreads();
+  float* wl = wsc + wave * 144;
+  int* jl = reinterpret_cast<int*>(wl + 64);
+  float* dl = wl + 128;
+  const int le = lane >> HLOG, lh = lane & (H - 1);    // edge-role coordinates
+  const int hk = lane >> (6 - HLOG), c0 = lane * CPL;  // channel-role coordinates
+  const unsigned row_bytes = __builtin_amdgcn_readfirstlane((unsigned)g.HC * 4u), lane_off = (unsigned)c0 * 4u;
+  const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z + zbase * g.HC), 0, N * (int)row_bytes, 0x00020000);
+  const int i0 = blockIdx.y * npb, i1 = min(N, i0 + npb);
+  // lane k holds the edge range of the k-th node this wave will visit (npb <= 64 * kTileWaves)
+  const int imine = min(i0 + wave + lane * kTileWaves, N - 1);
+  const int rp0v = g.rp_in[imine], rp1v = g.rp_in[imine + 1];
+  // wait for them here: left to the compiler, the wait lands at the top of the node loop, where it also waits for the
+  // previous node's output stores to be acknowledged
+  __builtin_amdgcn_s_waitcnt(kWaitVm0);
+  int trip = 0;
+  for (int i = i0 + wave; i < i1; i += kTileWaves, ++trip) {       // i is wave-uniform
+    const long node = rbase + i;
+    const float adl = ad_l[i * H + lh];
+    const int e0 = __builtin_amdgcn_readlane(rp0v, trip), e1 = __builtin_amdgcn_readlane(rp1v, trip);
+    const bool single = (e1 - e0) <= EPW;
+    // The first GB source rows are requested before the softmax over the edges is worked out (their indices come
+    // straight from the CSR), so that work runs under the rows' L2 round trip instead of in front of it.
+    const int n0 = min(EPW, e1 - e0);
+    float z0[GB][CPL];
+#pragma unroll
+    for (int q = 0; q < GB; q += 4) {
+      if (q < n0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int jr = src_l[e0 + q + u];
+          const int jj = q + u < n0 ? jr : N;       // row N is past the end of the buffer: nothing is fetched
+          load_row_buf<CPL>(zrs, mad_u24((unsigned)jj, row_bytes, lane_off), z0[q + u]);
+        }
+      }
+    }
+    float mx = -INFINITY, s_last = -INFINITY;
+    int j_last = N;
+    for (int base = e0; base < e1; base += EPW) {
+      const int e = base + le;
+      const bool valid = e < e1;
+      const int j = valid ? src_l[e] : N;
+      const float sv = valid ? lrelu(as_l[j * H + lh] + adl, g.slope) : -INFINITY;
+      mx = fmaxf(mx, sv);
+      s_last = sv; j_last = j;
+    }
+    mx = strided_reduce<true>(mx, H);
+    float den = 0.f, acc[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) acc[k] = 0.f;
+    for (int base = e0; base < e1; base += EPW) {
+      const int e = base + le;
+      const bool valid = e < e1;
+      float sv = s_last;
+      int j = j_last;
+      if (!single) {
+        j = valid ? src_l[e] : N;
+        sv = valid ? lrelu(as_l[j * H + lh] + adl, g.slope) : -INFINITY;
+      }
+      const float ex = valid ? __expf(sv - mx) : 0.f;
+      den += ex;
+      float w = ex;
+      if (g.att_drop.p > 0.f && valid) w *= dropout_keep(g.att_drop, ((uint64_t)r * E + e) * H + lh);
+      wave_lds_sync();
+      wl[lane] = w;
+      if (lh == 0) jl[le] = j;
+      wave_lds_sync();
+      const int n = min(EPW, e1 - base);
+      const bool first = base == e0;
+#pragma unroll
+      for (int qb = 0; qb < EPW; qb += GB) {
+        if (qb < n) {
+          // rows of one batch are all requested before the first is used: one round trip per batch
+          float zz[GB][CPL];
+          if (!(qb == 0 && first)) {
+#pragma unroll
+            for (int q = 0; q < GB; q += 4) {
+              if (qb + q < n) {            // slots n.. of the last group hold weight 0 and the out-of-range row
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                  load_row_buf<CPL>(zrs, mad_u24((unsigned)jl[qb + q + u], row_bytes, lane_off), qb == 0 ? z0[q + u] : zz[q + u]);
+              }
+            }
+          }
+          asm volatile("" ::: "memory");   // keep the loads above the first use
+#pragma unroll
+          for (int q = 0; q < GB; q += 4) {
+            if (qb + q < n) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float w4 = wl[(qb + q + u) * H + hk];
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) acc[k] = fmaf(w4, qb == 0 ? z0[q + u][k] : zz[q + u][k], acc[k]);
+              }
+            }
+          }
+          // every load issued so far has been consumed; saying so keeps the compiler from guarding the next
+          // batch's registers with waits on loads it cannot prove finished
+          __builtin_amdgcn_s_waitcnt(kWaitVm0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(kWaitVm0);   // (no load is in flight here on any path; stated for the compiler as above)
+    den = strided_reduce<false>(den, H);
+    wave_lds_sync();
+    if (le == 0) { smax[node * H + lh] = mx; sden[node * H + lh] = den; dl[lh] = den; }
+    wave_lds_sync();
+    const float inv = __builtin_amdgcn_rcpf(dl[hk] + 1e-16f);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) acc[k] *= inv;
+    store_row<CPL>(agg + node * g.HC + c0, acc);
+  }
+}
+
+template <int CPL, int HLOG>
+__global__ __launch_bounds__(kTileWaves * 64) void gat_bwd_source_tile_kernel(GatK g, int npb, const float* __restrict__ Z,
+                                                                              const float* __restrict__ a_s,
+                                                                              const float* __restrict__ a_d,
+                                                                              const float* __restrict__ smax,
+                                                                              const float* __restrict__ sden,
+                                                                              const float* __restrict__ dagg, const float* __restrict__ Dn,
+                                                                              float* __restrict__ dZ, float* __restrict__ da_s,
+                                                                              float* __restrict__ ds_edge) {
+  constexpr int H = 1 << HLOG, EPW = 64 >> HLOG, LPH = 64 >> HLOG;
+  constexpr int RB = CPL <= 2 ? 8 : 4, GB = EPW < RB ? EPW : RB;   // rows in flight per wave
+  g.att_drop = dropout_resolve(g.att_drop);
+  extern __shared__ float lds[];
+  const int N = g.N, E = g.E, NH = N * H;
+  float* as_l = lds;                                   // [N*H] source logits
+  float* ad_l = as_l + NH;                             // [N*H] target logits
+  float* mx_l = ad_l + NH;                             // [N*H] softmax maxima of the targets
+  float* id_l = mx_l + NH;                             // [N*H] 1 / (softmax denominators + 1e-16)
+  float* dn_l = id_l + NH;                             // [N*H] sum_c dAgg*agg of the targets
+  int* dst_l = reinterpret_cast<int*>(dn_l + NH);      // [E]
+  int* eid_l = dst_l + E;                              // [E]
+  float* wsc = reinterpret_cast<float*>(eid_l + E);    // per wave: weights [64], edge dot products [64], row indices [64]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = blockIdx.x;
+  const long rbase = (long)r * N;
+  const long zbase = g.z_shared ? 0 : rbase;
+  for (int t = threadIdx.x; t < NH; t += kTileWaves * 64) {
+    as_l[t] = a_s[zbase * H + t];
+    ad_l[t] = a_d[zbase * H + t];
+    mx_l[t] = smax[rbase * H + t];
+    id_l[t] = 1.0f / (sden[rbase * H + t] + 1e-16f);
+    dn_l[t] = Dn[rbase * H + t];
+  }
+  for (int t = threadIdx.x; t < E; t += kTileWaves * 64) { dst_l[t] = g.dst_out[t]; eid_l[t] = g.eid_out[t]; }
+  __syncthreads();
+  float* wl = wsc + wave * 192;
+  float* hl = wl + 64;
+  int* il = reinterpret_cast<int*>(wl + 128);
+  const int le = lane >> HLOG, lh = lane & (H - 1);
+  const int hk = lane >> (6 - HLOG), c0 = lane * CPL;
+  const unsigned row_bytes = __builtin_amdgcn_readfirstlane((unsigned)g.HC * 4u), lane_off = (unsigned)c0 * 4u;
+  const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dagg + rbase * g.HC), 0, N * (int)row_bytes, 0x00020000);
+  const long eslot0 = (long)r * E * H + lh;
+  const int j0 = blockIdx.y * npb, j1 = min(N, j0 + npb);
+  const int jmine = min(j0 + wave + lane * kTileWaves, N - 1);
+  const int rp0v = g.rp_out[jmine], rp1v = g.rp_out[jmine + 1];
+  __builtin_amdgcn_s_waitcnt(kWaitVm0);   // as in the forward kernel
+  int trip = 0;
+  for (int j = j0 + wave; j < j1; j += kTileWaves, ++trip) {       // j is wave-uniform
+    const long node = rbase + j;
+    float z[CPL], dz[CPL];
+    load_row<CPL>(Z + (zbase + j) * g.HC + c0, z);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) dz[k] = 0.f;
+    const float asl = as_l[j * H + lh];
+    float das = 0.f;
+    const int e0 = __builtin_amdgcn_readlane(rp0v, trip), e1 = __builtin_amdgcn_readlane(rp1v, trip);
+    for (int base = e0; base < e1; base += EPW) {
+      const int e = base + le;
+      const bool valid = e < e1;
+      const int it = valid ? dst_l[e] : N;           // row N is past the end of the buffer: its load returns 0 untouched
+      const int ih = (valid ? it : j) * H + lh;
+      const float raw = asl + ad_l[ih];
+      const float alpha = valid ? __expf(lrelu(raw, g.slope) - mx_l[ih]) * id_l[ih] : 0.f;
+      const long eslot = valid ? eslot0 + (long)eid_l[e] * H : 0;   // this edge's slot in by-target order
+      float keep = 1.f;
+      if (g.att_drop.p > 0.f && valid) keep = dropout_keep(g.att_drop, (uint64_t)eslot);
+      const float dnv = dn_l[ih];
+      wave_lds_sync();
+      wl[lane] = alpha * keep;
+      if (lh == 0) il[le] = it;
+      wave_lds_sync();
+      const int n = min(EPW, e1 - base);
+#pragma unroll
+      for (int qb = 0; qb < EPW; qb += GB) {
+        if (qb < n) {
+          float dg[GB][CPL];
+#pragma unroll
+          for (int q = 0; q < GB; q += 4) {
+            if (qb + q < n) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                load_row_buf<CPL>(drs, mad_u24((unsigned)il[qb + q + u], row_bytes, lane_off), dg[q + u]);
+            }
+          }
+          asm volatile("" ::: "memory");   // keep the loads above the first use
+#pragma unroll
+          for (int q = 0; q < GB; q += 4) {
+            if (qb + q < n) {
+              float pr[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float w4 = wl[(qb + q + u) * H + hk];
+                float p = 0.f;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) { dz[k] = fmaf(w4, dg[q + u][k], dz[k]); p = fmaf(dg[q + u][k], z[k], p); }
+                pr[u] = p;
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) pr[u] = group_sum(pr[u], LPH);
+              if ((lane & (LPH - 1)) == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) hl[(qb + q + u) * H + hk] = pr[u];
+              }
+            }
+          }
+          __builtin_amdgcn_s_waitcnt(kWaitVm0);   // as in the forward kernel: all of this batch's loads are consumed
+        }
+      }
+      wave_lds_sync();
+      if (valid) {
+        const float de = alpha * (keep * hl[lane] - dnv);
+        const float ds = de * (raw > 0.f ? 1.f : g.slope);
+        das += ds;
+        ds_edge[eslot] = ds;
+      }
+    }
+    das = strided_reduce<false>(das, H);
+    if (le == 0) da_s[node * H + lh] = das;
+    store_row<CPL>(dZ + node * g.HC + c0, dz);
+  }
 }
 
 // ---- node-streaming passes of the fast path ----------------------------------------------------------------
@@ -826,7 +1123,7 @@ inline int cpl_of(const GnnPlan& p) {
   } while (0)
 
 inline bool fast_edges(const GnnPlan& p) {
-  static const bool off = getenv("OCEAN_GAT_GENERIC") != nullptr;   // measurement aid: force the one-edge-at-a-time kernels
+  const bool off = getenv("OCEAN_GAT_GENERIC") != nullptr;   // test / measurement aid: force the one-edge-at-a-time kernels
   return !off && fast_heads(p) && cpl_of(p) * 64 == p.D && p.H <= 16;
 }
 inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
@@ -852,6 +1149,46 @@ inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
     else if (cpl__ == 4) hipLaunchKernelGGL((KERNEL<4>), grid__, block__, 0, st, g, hlog__, __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<8>), grid__, block__, 0, st, g, hlog__, __VA_ARGS__);                 \
     OCEAN_LAUNCH_CHECK();                                                                                 \
+  } while (0)
+
+// replica-block kernels: LDS bytes of the forward / backward table sets, and whether they apply
+inline size_t tile_lds_fwd(const GnnPlan& p, int E) {
+  return sizeof(float) * ((size_t)2 * p.N * p.H + E + 8 + (size_t)kTileWaves * 144);
+}
+inline size_t tile_lds_bwd(const GnnPlan& p, int E) {
+  return sizeof(float) * ((size_t)5 * p.N * p.H + 2 * (size_t)E + (size_t)kTileWaves * 192);
+}
+inline bool tile_edges(const GnnPlan& p, int E) {
+  const bool off = getenv("OCEAN_GAT_NO_TILE") != nullptr;   // test / measurement aid: keep the one-node-per-wave kernels
+  return !off && fast_edges(p) && tile_lds_bwd(p, E) <= 64 * 1024 && tile_lds_fwd(p, E) <= 64 * 1024;
+}
+// blocks: one per (replica, node range); node ranges only when there are too few replicas to fill the chip
+inline int tile_chunks(const GnnPlan& p) {
+  int c = (int)ceil_div(1024, p.R);
+  const int cmin = (int)ceil_div(p.N, 64 * kTileWaves);   // a wave keeps the edge ranges of its nodes in its 64 lanes
+  const int cmax = (int)ceil_div(p.N, kTileWaves);
+  c = c > cmax ? cmax : c;
+  return c < cmin ? cmin : c;
+}
+
+#define GAT_TILE_HEADS(KERNEL, CPLV, LDS, ...)                                                                               \
+  switch (hlog__) {                                                                                                          \
+    case 0: hipLaunchKernelGGL((KERNEL<CPLV, 0>), grid__, block__, LDS, st, g, npb__, __VA_ARGS__); break;                   \
+    case 1: hipLaunchKernelGGL((KERNEL<CPLV, 1>), grid__, block__, LDS, st, g, npb__, __VA_ARGS__); break;                   \
+    case 2: hipLaunchKernelGGL((KERNEL<CPLV, 2>), grid__, block__, LDS, st, g, npb__, __VA_ARGS__); break;                   \
+    case 3: hipLaunchKernelGGL((KERNEL<CPLV, 3>), grid__, block__, LDS, st, g, npb__, __VA_ARGS__); break;                   \
+    default: hipLaunchKernelGGL((KERNEL<CPLV, 4>), grid__, block__, LDS, st, g, npb__, __VA_ARGS__); break;                  \
+  }
+#define GAT_DISPATCH_TILE(KERNEL, LDS, ...)                                                                   \
+  do {                                                                                                         \
+    const int cpl__ = cpl_of(pl), hlog__ = ilog2(pl.H), ch__ = tile_chunks(pl);                                \
+    const int npb__ = (int)ceil_div(pl.N, ch__);                                                               \
+    const dim3 grid__(pl.R, ch__), block__(kTileWaves * 64);                                                   \
+    if (cpl__ == 1) { GAT_TILE_HEADS(KERNEL, 1, LDS, __VA_ARGS__) }                                            \
+    else if (cpl__ == 2) { GAT_TILE_HEADS(KERNEL, 2, LDS, __VA_ARGS__) }                                       \
+    else if (cpl__ == 4) { GAT_TILE_HEADS(KERNEL, 4, LDS, __VA_ARGS__) }                                       \
+    else { GAT_TILE_HEADS(KERNEL, 8, LDS, __VA_ARGS__) }                                                       \
+    OCEAN_LAUNCH_CHECK();                                                                                      \
   } while (0)
 
 // parameter table: in_w, in_b, then per layer (lin_w, att_src, att_dst, bias), then out_w, out_b
@@ -900,7 +1237,10 @@ int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features, const in
       GAT_STREAM_FAST(gat_scores_fast_kernel, ws + pl.Z[l], params[pg_layer(l, 1)], params[pg_layer(l, 2)], ws + pl.as_[l], ws + pl.ad[l]);
     else
       GAT_DISPATCH(gat_scores_kernel, g, ws + pl.Z[l], params[pg_layer(l, 1)], params[pg_layer(l, 2)], ws + pl.as_[l], ws + pl.ad[l]);
-    if (fast_edges(pl)) {
+    if (tile_edges(pl, s->E)) {
+      GAT_DISPATCH_TILE(gat_aggregate_tile_kernel, tile_lds_fwd(pl, s->E), ws + pl.Z[l], ws + pl.as_[l], ws + pl.ad[l], ws + pl.agg[l],
+                        ws + pl.smax[l], ws + pl.sden[l]);
+    } else if (fast_edges(pl)) {
       GAT_DISPATCH_FAST(gat_aggregate_fast_kernel, ws + pl.Z[l], ws + pl.as_[l], ws + pl.ad[l], ws + pl.agg[l], ws + pl.smax[l], ws + pl.sden[l]);
     } else {
       const int cpl = cpl_of(pl);
@@ -967,8 +1307,12 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
       GAT_DISPATCH(gat_bwd_dot_kernel, g, wb + pl.dagg, wf + pl.agg[l], wb + pl.Dn);
     }
     if (fast_edges(pl)) {
-      GAT_DISPATCH_FAST(gat_bwd_source_fast_kernel, wf + pl.Z[l], wf + pl.as_[l], wf + pl.ad[l], wf + pl.smax[l], wf + pl.sden[l],
-                        wb + pl.dagg, wb + pl.Dn, wb + pl.dZ, wb + pl.das, wb + pl.dse);
+      if (tile_edges(pl, s->E))
+        GAT_DISPATCH_TILE(gat_bwd_source_tile_kernel, tile_lds_bwd(pl, s->E), wf + pl.Z[l], wf + pl.as_[l], wf + pl.ad[l], wf + pl.smax[l],
+                          wf + pl.sden[l], wb + pl.dagg, wb + pl.Dn, wb + pl.dZ, wb + pl.das, wb + pl.dse);
+      else
+        GAT_DISPATCH_FAST(gat_bwd_source_fast_kernel, wf + pl.Z[l], wf + pl.as_[l], wf + pl.ad[l], wf + pl.smax[l], wf + pl.sden[l],
+                          wb + pl.dagg, wb + pl.Dn, wb + pl.dZ, wb + pl.das, wb + pl.dse);
       hipLaunchKernelGGL(gat_bwd_target_sum_kernel, dim3(egrid(rows * H)), dim3(256), 0, st, g, wb + pl.dse, wb + pl.dad);
       OCEAN_LAUNCH_CHECK();
     } else {

@@ -42,13 +42,29 @@ CASES = [  # N, G, D, H, layers, B, avg_deg
     (32, 8, 256, 8, 2, 2, 6.0),    # 4 channels per lane
     (24, 8, 512, 4, 1, 2, 5.0),    # 8 channels per lane
     (20, 6, 64, 1, 1, 3, 4.0),     # one layer, one head: the pooled layer has the residual and the shared first transform
+    (256, 12, 128, 4, 2, 5, 8.0),  # the headline graph size: one replica per block, 16 nodes per wave
+    (500, 12, 128, 4, 2, 1, 3.0),  # one replica cut into node ranges
 ]
+
+
+# kernel families of the edge phase: replica-per-block with LDS tables (default where the tables fit), one node per
+# wave with edge-parallel lanes, and the generic one-edge-at-a-time kernels (the library reads these switches per call)
+PATHS = {"replica_block": {}, "node_per_wave": {"OCEAN_GAT_NO_TILE": "1"}, "generic": {"OCEAN_GAT_GENERIC": "1"}}
+
+
+def _select(monkeypatch, path):
+    for k in ("OCEAN_GAT_NO_TILE", "OCEAN_GAT_GENERIC"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in PATHS[path].items():
+        monkeypatch.setenv(k, v)
 
 
 @pytest.mark.parametrize("N,G,D,H,layers,B,deg", CASES)
 @pytest.mark.parametrize("dedupe", [True, False])
-def test_forward_backward_matches_oracle(N, G, D, H, layers, B, deg, dedupe):
+@pytest.mark.parametrize("path", list(PATHS))
+def test_forward_backward_matches_oracle(N, G, D, H, layers, B, deg, dedupe, path, monkeypatch):
     from ocean.models.components import DeviceGraph, GraphNeuralNetwork
+    _select(monkeypatch, path)
     m = GraphNeuralNetwork(G, D, layers, H, dropout=0.0, batch_norm=False)
     sd = synth.fill_state_dict(m.state_dict(), 11)
     m.load_state_dict(sd)
@@ -117,11 +133,13 @@ def test_dropout_replicas_differ_and_stay_finite():
 
 
 @pytest.mark.parametrize("D,H,deg", [(128, 4, 20.0), (64, 16, 6.0), (24, 3, 3.0)])
-def test_dropout_backward_matches_finite_differences(D, H, deg):
+@pytest.mark.parametrize("path", ["replica_block", "node_per_wave"])
+def test_dropout_backward_matches_finite_differences(D, H, deg, path, monkeypatch):
     """With dropout on, forward and backward must regenerate the same masks: under a fixed seed the forward is a
     deterministic function of the parameters, and its directional derivative (central differences) must agree
     with the analytic gradient."""
     from ocean.models.components import DeviceGraph, GraphNeuralNetwork
+    _select(monkeypatch, path)
     N, B = 48, 3
     m = GraphNeuralNetwork(12, D, 2, H, dropout=0.3, batch_norm=False)
     m.load_state_dict(synth.fill_state_dict(m.state_dict(), 5))
