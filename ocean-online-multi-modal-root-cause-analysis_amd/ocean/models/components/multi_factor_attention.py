@@ -91,7 +91,9 @@ class _MfaFunction(torch.autograd.Function):
         t, s, l, ws, *params = ctx.saved_tensors
         sh = ctx.sh
         wb = torch.empty(L.ocean_mfa_bwd_workspace(ctypes.byref(sh)), device=t.device, dtype=torch.float32)
-        grads = _hip.zero_grads_like(params)
+        # one zero-filled flat buffer carries the live gradients and the dead tensors' zeros (a single fill)
+        both = _hip.zero_grads_like(list(params) + list(ctx.dead))
+        grads, dead_zero = both[:len(params)], both[len(params):]
         dt = torch.empty_like(t) if ctx.needs_input_grad[0] else None
         ds = torch.empty_like(s) if ctx.needs_input_grad[1] else None
         dl = torch.empty_like(l) if ctx.needs_input_grad[2] else None
@@ -100,8 +102,7 @@ class _MfaFunction(torch.autograd.Function):
                                    _hip.dev_ptr(dout.contiguous(), "grad_output"), _hip.ptr_table(grads, "mfa grad"),
                                    _hip.dev_ptr(dt), _hip.dev_ptr(ds), _hip.dev_ptr(dl), _hip.stream()), "ocean_mfa_bwd")
         live = tuple(g if ctx.needs_input_grad[5 + i] else None for i, g in enumerate(grads))
-        dead = tuple(torch.zeros_like(p) if ctx.needs_input_grad[5 + len(grads) + i] else None
-                     for i, p in enumerate(ctx.dead))
+        dead = tuple(z if ctx.needs_input_grad[5 + len(grads) + i] else None for i, z in enumerate(dead_zero))
         return (dt, ds, dl, None, None) + live + dead
 
 

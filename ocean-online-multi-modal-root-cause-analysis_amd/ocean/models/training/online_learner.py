@@ -206,6 +206,7 @@ class OnlineLearner:
         self.pinned_staging = True
         self._stager: Optional[BatchStager] = None
         self._prefetch_next: Optional[List[DatasetSample]] = None
+        self._mods = None
         self._prefetched = None
         self._graph_seen: Dict[Any, int] = defaultdict(int)
 
@@ -219,6 +220,18 @@ class OnlineLearner:
             if k in losses and k not in out:
                 out[k] = float(losses[k])
         return out
+
+    def _train_mode(self) -> None:
+        """model.train() as the reference calls it before every update (online_learner.py:304,375), skipped when
+        every module already is in training mode: the recursive call walks ~200 modules and costs more host time
+        than the kernels of a small update take to launch."""
+        if not (self.model.training and all(m.training for m in self._modules_list())):
+            self.model.train()
+
+    def _modules_list(self):
+        if self._mods is None:
+            self._mods = list(self.model.modules())
+        return self._mods
 
     def _apply_update(self, total_loss: torch.Tensor) -> None:
         self.optimizer.zero_grad()
@@ -235,7 +248,7 @@ class OnlineLearner:
         self.update_count += 1
 
     def process_sample(self, sample: DatasetSample, update_model: bool = True) -> Dict[str, float]:
-        self.model.train()
+        self._train_mode()
         outputs = self.model(sample.metrics.unsqueeze(0), sample.graph, sample.logs.unsqueeze(0))
         losses = self.model.compute_loss(outputs, sample.label.unsqueeze(0))
         if update_model:
@@ -260,7 +273,7 @@ class OnlineLearner:
         update, and a following process_batch(prefetch) call with that same list object starts on staged data."""
         if not batch_samples:
             return {}
-        self.model.train()
+        self._train_mode()
         service_graph = batch_samples[0].graph          # one graph for the batch (online_learner.py:382-383)
         staged = self._take_staged(batch_samples)
         if staged is not None:
@@ -300,7 +313,7 @@ class OnlineLearner:
     def process_tensors(self, metrics: torch.Tensor, service_graph, logs: torch.Tensor, labels: torch.Tensor) -> Dict[str, float]:
         """process_batch on already-collated tensors ([B,T,F], graph, [B,768], [B,S]); tensors that
         already live on the model's device are used in place (no host staging)."""
-        self.model.train()
+        self._train_mode()
         host = self._graph_step(metrics, service_graph, logs, labels) if self.use_hip_graph else None
         if host is None:
             outputs = self.model(metrics, service_graph, logs)

@@ -63,8 +63,22 @@ class FusedAdam(torch.optim.Optimizer):
         state_dict() and push a changed learning rate to the device."""
         for st in self.state.values():
             if st:
-                st["step"] += 1
+                st["step"] = int(st["step"]) + 1
         self.sync_lr()
+
+    def state_dict(self):
+        """torch.optim.Adam's layout: 'step' leaves as a float tensor, as Adam writes it."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if "step" in st and not torch.is_tensor(st["step"]):
+                st["step"] = torch.tensor(float(st["step"]))
+        return sd
+
+    def load_state_dict(self, state_dict) -> None:
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if st and torch.is_tensor(st.get("step")):
+                st["step"] = int(st["step"])
 
     def sync_lr(self) -> None:
         if self._lr_dev is not None:
@@ -90,11 +104,14 @@ class FusedAdam(torch.optim.Optimizer):
                     raise _hip.OceanHipError("FusedAdam needs contiguous fp32 parameters and gradients on the GPU")
                 st = self.state[p]
                 if not st:
-                    st["step"] = torch.tensor(0.0)
+                    st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
-                st["step"] += 1
-                by_step.setdefault(int(st["step"]), []).append((p, p.grad, st["exp_avg"], st["exp_avg_sq"]))
+                # the count is a Python int while training (a tensor only right after loading a torch.optim.Adam
+                # checkpoint): 126 CPU-tensor increments and reads per step were a measurable part of the host time
+                k = int(st["step"]) + 1
+                st["step"] = k
+                by_step.setdefault(k, []).append((p, p.grad, st["exp_avg"], st["exp_avg_sq"]))
             if not by_step:
                 continue
             device = next(iter(by_step.values()))[0][0].device
