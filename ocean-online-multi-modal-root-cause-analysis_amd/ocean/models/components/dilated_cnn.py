@@ -208,8 +208,7 @@ class DilatedCNN(nn.Module):
         out = _DcnnFunction.apply(x, self, *self._param_list())
         if self.training:
             with torch.no_grad():
-                for bn in self._bn_modules():
-                    bn.num_batches_tracked += 1
+                torch._foreach_add_([bn.num_batches_tracked for bn in self._bn_modules()], 1)   # one launch for all layers
         return out
 
     def compute_receptive_field(self) -> int:

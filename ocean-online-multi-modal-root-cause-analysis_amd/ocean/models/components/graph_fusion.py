@@ -239,27 +239,30 @@ class GraphFusionModule(nn.Module):
             if cm.training and cm.negatives == "bank":
                 cm._update_memory_bank(projections)
             results["projections"] = projections
-            results["mutual_information"] = self._mutual_information(fused, processed) if self.compute_mutual_information else {}
+            results["mutual_information"] = self._mutual_information(fused, X) if self.compute_mutual_information else {}
         return results
 
-    def _mutual_information(self, fused, processed) -> Dict[str, torch.Tensor]:
-        """MINE estimates of graph_fusion.py:475-501 (diagnostics only: they enter no loss)."""
-        out = {}
+    def _mutual_information(self, fused, X) -> Dict[str, torch.Tensor]:
+        """MINE estimates of graph_fusion.py:475-501 (diagnostics only: they enter no loss).  X is [B, 3, E], the
+        processed temporal / spatial / log features.  The three modalities go through the estimator as one
+        [6B, 2E] batch; the three permutations are still drawn one after the other, as the reference draws them."""
         w0, b0, w1, b1 = (p.detach() for p in (self.mi_estimator[0].weight, self.mi_estimator[0].bias,
                                                self.mi_estimator[2].weight, self.mi_estimator[2].bias))
         B, E = fused.shape
         with torch.no_grad():
-            f = fused.detach()
-            for k in ("temporal", "spatial", "log"):
-                m = processed[k].detach()
-                perm = torch.randperm(B, device=f.device)
-                pairs = torch.cat([torch.cat([f, m], 1), torch.cat([f, m[perm]], 1)], 0).contiguous()
-                hid = torch.empty(2 * B, E, device=f.device)
-                _hip.gemm(pairs, w0, hid, 2 * B, E, 2 * E, bias=b0, relu=True)
-                sc = torch.empty(2 * B, 1, device=f.device)
-                _hip.gemm(hid, w1, sc, 2 * B, 1, E, bias=b1)
-                out[f"{k}_mi"] = sc[:B].mean() - torch.log(torch.exp(sc[B:]).mean() + 1e-8)
-        return out
+            dev = fused.device
+            perms = torch.stack([torch.randperm(B, device=dev) for _ in range(3)])            # [3, B]
+            m = X.detach().permute(1, 0, 2)                                                    # [3, B, E]
+            shuffled = m[torch.arange(3, device=dev)[:, None], perms]                          # [3, B, E]
+            left = fused.detach().unsqueeze(0).expand(3, B, E).repeat(1, 2, 1)                 # [3, 2B, E]: joint rows, marginal rows
+            pairs = torch.cat([left, torch.cat([m, shuffled], 1)], 2).reshape(6 * B, 2 * E)
+            hid = torch.empty(6 * B, E, device=dev)
+            _hip.gemm(pairs, w0, hid, 6 * B, E, 2 * E, bias=b0, relu=True)
+            sc = torch.empty(6 * B, 1, device=dev)
+            _hip.gemm(hid, w1, sc, 6 * B, 1, E, bias=b1)
+            sc = sc.view(3, 2, B)
+            mi = sc[:, 0].mean(1) - torch.log(torch.exp(sc[:, 1]).mean(1) + 1e-8)
+        return {f"{k}_mi": mi[i] for i, k in enumerate(("temporal", "spatial", "log"))}
 
     def get_fusion_analysis(self, temporal_features, spatial_features, log_features) -> Dict[str, Any]:
         with torch.no_grad():

@@ -6,7 +6,7 @@ from ocean.models.components import DilatedCNN
 
 B, T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 128
 torch.manual_seed(0)
-m = DilatedCNN(12, None, 3, None, dropout=0.0, output_dim=128).cuda().train()
+m = DilatedCNN(12, None, 3, None, dropout=float(sys.argv[3]) if len(sys.argv) > 3 else 0.0, output_dim=128).cuda().train()
 x = torch.randn(B, T, 12, device="cuda")
 gw = torch.randn(B, 128, device="cuda")
 for it in range(3):
