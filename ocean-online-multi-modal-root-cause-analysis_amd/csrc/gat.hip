@@ -424,8 +424,23 @@ __device__ __forceinline__ void load_row_buf(__amdgpu_buffer_rsrc_t rs, unsigned
   }
 }
 
+// Block id -> (replica, node range).  The node ranges of one replica must share an L2 and run at the same time: a
+// replica's rows are gathered ~9 times over, and an XCD's 64 resident blocks on 64 different replicas of 128 KB
+// overflow its 4 MB L2 (measured: 5x the compulsory fetch).  Blocks are dealt to the 8 XCDs round-robin by id, so
+// ids that differ by 8 are neighbours on one XCD: those become the ranges of one replica.
+__device__ __forceinline__ void tile_block(unsigned id, int R, int chunks, int& r, int& chunk) {
+  if ((R & 7) == 0) {
+    const unsigned per = 8u * (unsigned)chunks;
+    r = (int)((id / per) * 8u + (id & 7u));
+    chunk = (int)((id >> 3) % (unsigned)chunks);
+  } else {
+    r = (int)(id / (unsigned)chunks);
+    chunk = (int)(id % (unsigned)chunks);
+  }
+}
+
 template <int CPL, int HLOG>
-__global__ __launch_bounds__(kTileWaves * 64) void gat_aggregate_tile_kernel(GatK g, int npb, const float* __restrict__ Z,
+__global__ __launch_bounds__(kTileWaves * 64) void gat_aggregate_tile_kernel(GatK g, int npb, int chunks, const float* __restrict__ Z,
                                                                              const float* __restrict__ a_s,
                                                                              const float* __restrict__ a_d, float* __restrict__ agg,
                                                                              float* __restrict__ smax, float* __restrict__ sden) {
@@ -440,7 +455,8 @@ __global__ __launch_bounds__(kTileWaves * 64) void gat_aggregate_tile_kernel(Gat
   float* wsc = reinterpret_cast<float*>(src_l + E + GB);      // per wave: weights [64], row indices [64], denominators [16]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = blockIdx.x;
+  int r, chunk;
+  tile_block(blockIdx.x, g.R, chunks, r, chunk);
   const long rbase = (long)r * N;
   const long zbase = g.z_shared ? 0 : rbase;
   for (int t = threadIdx.x; t < N * H; t += kTileWaves * 64) { as_l[t] = a_s[zbase * H + t]; ad_l[t] = a_d[zbase * H + t]; }
@@ -453,7 +469,7 @@ __global__ __launch_bounds__(kTileWaves * 64) void gat_aggregate_tile_kernel(Gat
   const int hk = lane >> (6 - HLOG), c0 = lane * CPL;  // channel-role coordinates
   const unsigned row_bytes = __builtin_amdgcn_readfirstlane((unsigned)g.HC * 4u), lane_off = (unsigned)c0 * 4u;
   const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z + zbase * g.HC), 0, N * (int)row_bytes, 0x00020000);
-  const int i0 = blockIdx.y * npb, i1 = min(N, i0 + npb);
+  const int i0 = chunk * npb, i1 = min(N, i0 + npb);
   // lane k holds the edge range of the k-th node this wave will visit (npb <= 64 * kTileWaves)
   const int imine = min(i0 + wave + lane * kTileWaves, N - 1);
   const int rp0v = g.rp_in[imine], rp1v = g.rp_in[imine + 1];
@@ -560,7 +576,7 @@ __global__ __launch_bounds__(kTileWaves * 64) void gat_aggregate_tile_kernel(Gat
 }
 
 template <int CPL, int HLOG>
-__global__ __launch_bounds__(kTileWaves * 64) void gat_bwd_source_tile_kernel(GatK g, int npb, const float* __restrict__ Z,
+__global__ __launch_bounds__(kTileWaves * 64) void gat_bwd_source_tile_kernel(GatK g, int npb, int chunks, const float* __restrict__ Z,
                                                                               const float* __restrict__ a_s,
                                                                               const float* __restrict__ a_d,
                                                                               const float* __restrict__ smax,
@@ -583,7 +599,8 @@ __global__ __launch_bounds__(kTileWaves * 64) void gat_bwd_source_tile_kernel(Ga
   float* wsc = reinterpret_cast<float*>(eid_l + E);    // per wave: weights [64], edge dot products [64], row indices [64]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = blockIdx.x;
+  int r, chunk;
+  tile_block(blockIdx.x, g.R, chunks, r, chunk);
   const long rbase = (long)r * N;
   const long zbase = g.z_shared ? 0 : rbase;
   for (int t = threadIdx.x; t < NH; t += kTileWaves * 64) {
@@ -603,7 +620,7 @@ __global__ __launch_bounds__(kTileWaves * 64) void gat_bwd_source_tile_kernel(Ga
   const unsigned row_bytes = __builtin_amdgcn_readfirstlane((unsigned)g.HC * 4u), lane_off = (unsigned)c0 * 4u;
   const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dagg + rbase * g.HC), 0, N * (int)row_bytes, 0x00020000);
   const long eslot0 = (long)r * E * H + lh;
-  const int j0 = blockIdx.y * npb, j1 = min(N, j0 + npb);
+  const int j0 = chunk * npb, j1 = min(N, j0 + npb);
   const int jmine = min(j0 + wave + lane * kTileWaves, N - 1);
   const int rp0v = g.rp_out[jmine], rp1v = g.rp_out[jmine + 1];
   __builtin_amdgcn_s_waitcnt(kWaitVm0);   // as in the forward kernel
@@ -1165,6 +1182,9 @@ inline bool tile_edges(const GnnPlan& p, int E) {
 // blocks: one per (replica, node range); node ranges only when there are too few replicas to fill the chip
 inline int tile_chunks(const GnnPlan& p) {
   int c = (int)ceil_div(1024, p.R);
+  // keep the replicas in flight on one XCD (64 resident blocks) within half of its 4 MB L2
+  const long l2c = ceil_div((long)64 * p.N * p.D * 4, (long)2 << 20);
+  if (l2c > c) c = (int)l2c;
   const int cmin = (int)ceil_div(p.N, 64 * kTileWaves);   // a wave keeps the edge ranges of its nodes in its 64 lanes
   const int cmax = (int)ceil_div(p.N, kTileWaves);
   c = c > cmax ? cmax : c;
@@ -1173,17 +1193,17 @@ inline int tile_chunks(const GnnPlan& p) {
 
 #define GAT_TILE_HEADS(KERNEL, CPLV, LDS, ...)                                                                               \
   switch (hlog__) {                                                                                                          \
-    case 0: hipLaunchKernelGGL((KERNEL<CPLV, 0>), grid__, block__, LDS, st, g, npb__, __VA_ARGS__); break;                   \
-    case 1: hipLaunchKernelGGL((KERNEL<CPLV, 1>), grid__, block__, LDS, st, g, npb__, __VA_ARGS__); break;                   \
-    case 2: hipLaunchKernelGGL((KERNEL<CPLV, 2>), grid__, block__, LDS, st, g, npb__, __VA_ARGS__); break;                   \
-    case 3: hipLaunchKernelGGL((KERNEL<CPLV, 3>), grid__, block__, LDS, st, g, npb__, __VA_ARGS__); break;                   \
-    default: hipLaunchKernelGGL((KERNEL<CPLV, 4>), grid__, block__, LDS, st, g, npb__, __VA_ARGS__); break;                  \
+    case 0: hipLaunchKernelGGL((KERNEL<CPLV, 0>), grid__, block__, LDS, st, g, npb__, ch__, __VA_ARGS__); break;                   \
+    case 1: hipLaunchKernelGGL((KERNEL<CPLV, 1>), grid__, block__, LDS, st, g, npb__, ch__, __VA_ARGS__); break;                   \
+    case 2: hipLaunchKernelGGL((KERNEL<CPLV, 2>), grid__, block__, LDS, st, g, npb__, ch__, __VA_ARGS__); break;                   \
+    case 3: hipLaunchKernelGGL((KERNEL<CPLV, 3>), grid__, block__, LDS, st, g, npb__, ch__, __VA_ARGS__); break;                   \
+    default: hipLaunchKernelGGL((KERNEL<CPLV, 4>), grid__, block__, LDS, st, g, npb__, ch__, __VA_ARGS__); break;                  \
   }
 #define GAT_DISPATCH_TILE(KERNEL, LDS, ...)                                                                   \
   do {                                                                                                         \
     const int cpl__ = cpl_of(pl), hlog__ = ilog2(pl.H), ch__ = tile_chunks(pl);                                \
     const int npb__ = (int)ceil_div(pl.N, ch__);                                                               \
-    const dim3 grid__(pl.R, ch__), block__(kTileWaves * 64);                                                   \
+    const dim3 grid__((unsigned)pl.R * ch__), block__(kTileWaves * 64);                                                   \
     if (cpl__ == 1) { GAT_TILE_HEADS(KERNEL, 1, LDS, __VA_ARGS__) }                                            \
     else if (cpl__ == 2) { GAT_TILE_HEADS(KERNEL, 2, LDS, __VA_ARGS__) }                                       \
     else if (cpl__ == 4) { GAT_TILE_HEADS(KERNEL, 4, LDS, __VA_ARGS__) }                                       \
