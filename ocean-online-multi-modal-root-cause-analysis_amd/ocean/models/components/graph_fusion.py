@@ -86,13 +86,21 @@ class ContrastiveLearningModule(nn.Module):
         names = list(projections.keys())
         losses = {}
         neg = self._get_negatives() if self.negatives == "bank" else None
+        gathered = {}
+        if neg is None and self.gather_positives is not None and len(names) > 1:
+            # data parallel: every modality but the first serves as the positive side of some pair; one collective
+            # over their column-wise concatenation (and one reduce-scatter in backward) instead of one per pair
+            pos = names[1:]
+            P = projections[pos[0]].shape[1]
+            allp = self.gather_positives(torch.cat([projections[n] for n in pos], 1))
+            gathered = {n: allp[:, k * P:(k + 1) * P].contiguous() for k, n in enumerate(pos)}
         for i, a in enumerate(names):
             for b in names[i + 1:]:
                 pa, pb = projections[a], projections[b]
                 if neg is not None:
                     losses[f"{a}_{b}_contrastive"] = ops.infonce(pa, pb, neg, self.infonce_loss.temperature)
                 else:
-                    allb = self.gather_positives(pb) if self.gather_positives is not None else pb
+                    allb = gathered.get(b, pb)
                     losses[f"{a}_{b}_contrastive"] = ops.infonce(pa, allb, None, self.infonce_loss.temperature,
                                                                   label_offset=self.rank_row_offset(pa.shape[0]))
         return losses
