@@ -461,7 +461,7 @@ inline int env_int(const char* name, int dflt) {
 // reduction rows per block of a split row reduction), OCEAN_GEMM_WG_BIGK (row reductions at least this long use
 // 128x128 tiles)
 inline int small_bk() { static const int v = env_int("OCEAN_GEMM_SMALL_BK", 16) == 32 ? 32 : 16; return v; }
-inline int wg_chunk() { static const int v = env_int("OCEAN_GEMM_WG_CHUNK", 256); return v < 16 ? 16 : v; }
+inline int wg_chunk() { static const int v = env_int("OCEAN_GEMM_WG_CHUNK", 128); return v < 16 ? 16 : v; }
 inline long wg_big_k() { static const int v = env_int("OCEAN_GEMM_WG_BIGK", 8192); return v; }
 
 template <bool AKM, bool BKN>
