@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
 
   // per-thread load coordinates that do not change over the reduction
   int a_row[A_F4], a_col[A_F4], a_t[A_F4];
-  int b_row[B_F4], b_col[B_F4];
+  int b_row[B_F4], b_col[B_F4], b_rt[B_F4];
   unsigned a_voff[A_F4], b_voff[B_F4];   // loop-invariant part of the byte offset (ALIGNED path)
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
     } else {
       a_row[i] = idx / (BK / 4); a_col[i] = (idx % (BK / 4)) * 4;
       a_t[i] = (p.T > 0) ? (m0 + a_row[i]) % p.T : 0;
-      a_voff[i] = (unsigned)a_col[i] * 4u;
+      a_voff[i] = (unsigned)((m0 + a_row[i]) * p.lda + a_col[i]) * 4u;   // row shift and k offset are wave-uniform
     }
   }
 #pragma unroll
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
     if (BKN) {
       b_row[i] = idx / (BN / 4); b_col[i] = (idx % (BN / 4)) * 4;
       b_voff[i] = (unsigned)(b_row[i] * p.ldb + n0 + b_col[i]) * 4u;
+      b_rt[i] = (AKM && p.T > 0) ? b_row[i] % p.T : 0;
     } else {
       b_row[i] = idx / (BK / 4); b_col[i] = (idx % (BK / 4)) * 4;
       b_voff[i] = (unsigned)((n0 + b_row[i]) * p.ldb + b_col[i]) * 4u;
@@ -151,13 +152,25 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
   // wave-uniform description of reduction tile `it`
   struct TileAt { int tap, kk0, shift, kt; bool valid; };
   const unsigned t_lim = p.T > 0 ? (unsigned)p.T : 0x7FFFFFFFu;
-  auto tile_at = [&](int it) {
+  // Tiles are visited strictly in order, so their coordinates are advanced, not recomputed: no division per tile.
+  // (All of this is wave-uniform and runs on the scalar unit.)
+  int g_it = 0, g_tap = AKM ? ztap : 0, g_kk0 = k_begin;
+  int g_kt = (AKM && p.T > 0) ? k_begin % p.T : 0;
+  auto next_tile = [&]() {
     TileAt t;
-    t.tap = AKM ? ztap : it / nk;
-    t.kk0 = k_begin + (it % nk) * BK;
-    t.shift = (p.T > 0) ? p.shift0 + t.tap * p.shift_step : 0;
-    t.kt = (AKM && p.T > 0) ? t.kk0 % p.T : 0;
-    t.valid = it < n_iter;
+    t.tap = g_tap;
+    t.kk0 = g_kk0;
+    t.shift = (p.T > 0) ? p.shift0 + g_tap * p.shift_step : 0;
+    t.kt = g_kt;
+    t.valid = g_it < n_iter;
+    ++g_it;
+    g_kk0 += BK;
+    if (AKM) {
+      if (p.T > 0) { g_kt += BK; while (g_kt >= p.T) g_kt -= p.T; }
+    } else if (g_kk0 >= k_begin + nk * BK) {
+      g_kk0 = k_begin;
+      ++g_tap;
+    }
     return t;
   };
 
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
       } else {
         const int gm = m0 + a_row[i];
         const bool ok = t.valid && gm < p.M && t.kk0 + a_col[i] < k_end && (unsigned)(a_t[i] + t.shift) < t_lim;
-        const unsigned off = (unsigned)((gm + t.shift) * p.lda) * 4u + a_voff[i];
+        const unsigned off = a_voff[i] + (unsigned)(t.shift * p.lda * 4);
         ra[i] = buf_load(rsrc_a, ok ? off : kOob, t.kk0 * 4);
       }
       return;
@@ -202,16 +215,14 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
   auto load_b = [&](const TileAt& t, int i) {
     // time index of reduction row gk when the reduction runs over (sample, time) rows
     auto row_time = [&](int i2) {
-      int tt = t.kt + b_row[i2];
-      if (p.T >= BK) tt = tt >= p.T ? tt - p.T : tt;
-      else if (p.T > 0) tt %= p.T;
-      return tt;
+      const int tt = t.kt + b_rt[i2];          // both terms are below T
+      return tt >= p.T ? tt - p.T : tt;
     };
     if (ALIGNED) {
       if (BKN && AKM) {
         const int gk = t.kk0 + b_row[i];
         const bool ok = t.valid && gk < k_end && n0 + b_col[i] < p.N && (unsigned)(row_time(i) + t.shift) < t_lim;
-        const unsigned off = (unsigned)((gk + t.shift) * p.ldb + n0 + b_col[i]) * 4u;
+        const unsigned off = b_voff[i] + (unsigned)((t.kk0 + t.shift) * p.ldb * 4);   // lane part + wave-uniform part
         rb[i] = buf_load(rsrc_b, ok ? off : kOob, 0);
       } else if (BKN) {
         const bool ok = t.valid && t.kk0 + b_row[i] < k_end && n0 + b_col[i] < p.N;
@@ -273,8 +284,8 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
       Bd[(b_col[i] + 3) * LDB + b_row[i]] = rb[i].w;
     }
   };
-  auto load_tiles = [&](int it) {
-    const TileAt t = tile_at(it);
+  auto load_tiles = [&]() {
+    const TileAt t = next_tile();
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) load_a(t, i);
 #pragma unroll
@@ -301,9 +312,9 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
   // of tile it+1 are read, so the matrix pipe never waits on a load, an LDS write or a fragment read at an
   // iteration boundary.  Ring slot (it+1)%3 was last read as tile it-2, which every wave finished before it
   // passed the barrier of iteration it-1.
-  load_tiles(0);
+  load_tiles();
   store_tiles(0);
-  load_tiles(1);
+  load_tiles();
   __syncthreads();
 
   const int a_frag = wm * (BM / 2) + (lane & 31);
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
     const float* An = As + nbuf * BK * LDA + a_frag;
     const float* Bn = Bs + nbuf * BK * LDB + b_frag;
     const bool more = it + 1 < n_iter;
-    const TileAt t2 = tile_at(it + 2);
+    const TileAt t2 = next_tile();
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
