@@ -87,7 +87,9 @@ inline int pi_out(int L, int k) { return 2 + 5 * L + 5 * (L - 1) + k; }
 inline int pi_bn(const DcnnPlan& p, int j, int k) { return p.is_block[j] ? pi_block(p.li[j], k) : pi_trans(p.L, p.li[j], k); }
 
 // ------------------------------------------------------------------ kernels
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double n, const float* __restrict__ gamma,
+// stats: [2][C] sums, or - with nslots > 0 - nslots copies of them that are added up here (the convolution epilogue's
+// slot copies, when no other rank's sums have to be added in between)
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int nslots, double n, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
                                    float* __restrict__ shift, int C, int training, float eps, float momentum) {
@@ -95,8 +97,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double n, c
   if (c >= C) return;
   float mu, var;
   if (training) {
-    const double m = stats[c] / n;
-    double v = stats[C + c] / n - m * m;
+    double s1 = stats[c], s2 = stats[C + c];
+    for (int q = 1; q < nslots; ++q) { s1 += stats[(size_t)q * 2 * C + c]; s2 += stats[(size_t)q * 2 * C + C + c]; }
+    const double m = s1 / n;
+    double v = s2 / n - m * m;
     if (v < 0.0) v = 0.0;
     mu = (float)m; var = (float)v;
     const double unbiased = n > 1.0 ? v * n / (n - 1.0) : v;
@@ -331,11 +335,12 @@ inline int egrid(long n, int per = 256) {
   return (int)g;
 }
 
-int bn_finalize(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, float* const* params, float* ws, hipStream_t st) {
+int bn_finalize(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, float* const* params, float* ws, bool from_slots,
+                hipStream_t st) {
   const int C = pl.width[j];
   const double n = (double)(s->bn_count > 0 ? s->bn_count : pl.M);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st,
-                     reinterpret_cast<const double*>(ws + pl.stats[j]), n, params[pi_bn(pl, j, 1)], params[pi_bn(pl, j, 2)],
+                     reinterpret_cast<const double*>(ws + (from_slots ? pl.fslots[j] : pl.stats[j])), from_slots ? kStatSlots : 0, n, params[pi_bn(pl, j, 1)], params[pi_bn(pl, j, 2)],
                      params[pi_bn(pl, j, 3)], params[pi_bn(pl, j, 4)], ws + pl.mean[j], ws + pl.invstd[j],
                      ws + pl.scale[j], ws + pl.shift[j], C, s->training, s->eps, s->momentum);
   OCEAN_LAUNCH_CHECK();
@@ -367,7 +372,10 @@ int bn_apply_fwd(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, float* ws
 }
 
 // the convolution of BN layer j: input activation -> u_j, column statistics in the epilogue
-int conv_fwd(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, const float* in, float* const* params, float* ws, hipStream_t st) {
+// collapse: add the epilogue's slot copies into stats[j] (needed when the caller all-reduces that block over ranks
+// before the next phase; otherwise bn_finalize adds them itself)
+int conv_fwd(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, const float* in, float* const* params, float* ws, bool collapse,
+             hipStream_t st) {
   GemmP g = gemm_defaults();
   g.A = in; g.lda = pl.in_width[j]; g.C = ws + pl.u[j]; g.ldc = pl.width[j];
   g.M = pl.M; g.N = pl.width[j]; g.K = pl.in_width[j];
@@ -384,7 +392,7 @@ int conv_fwd(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, const float* 
     g.B = params[pi_trans(pl.L, pl.li[j], 0)]; g.ldb = pl.in_width[j];
   }
   OCEAN_TRY(ocean_launch_gemm(g, st));
-  if (s->training) {
+  if (s->training && collapse) {
     const int n2 = 2 * pl.width[j];
     hipLaunchKernelGGL(bn_stats_collapse_kernel, dim3(ceil_div(n2, 64)), dim3(64), 0, st,
                        reinterpret_cast<const double*>(ws + pl.fslots[j]), reinterpret_cast<double*>(ws + pl.stats[j]), n2);
@@ -442,13 +450,14 @@ int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* para
         OCEAN_LAUNCH_CHECK();
       }
       OCEAN_TRY(linear_fwd(x, s->F, params[0], params[1], ws + pl.h0, s->channels[0], pl.M, s->channels[0], s->F, 0, st));
-      OCEAN_TRY(conv_fwd(pl, s, 0, ws + pl.h0, params, ws, st));
+      OCEAN_TRY(conv_fwd(pl, s, 0, ws + pl.h0, params, ws, ph + 1 >= phase_hi, st));
     } else {
       const int j = ph - 1;   // finish BN layer j
-      OCEAN_TRY(bn_finalize(pl, s, j, params, ws, st));
+      // the statistics were collapsed (and possibly all-reduced by the caller) iff this call starts at this phase
+      OCEAN_TRY(bn_finalize(pl, s, j, params, ws, s->training && ph > phase_lo, st));
       OCEAN_TRY(bn_apply_fwd(pl, s, j, ws, pl.is_block[j] ? layer_input(pl, j, ws) : nullptr, st));
       if (ph < nph - 1) {
-        OCEAN_TRY(conv_fwd(pl, s, j + 1, ws + pl.a[j], params, ws, st));
+        OCEAN_TRY(conv_fwd(pl, s, j + 1, ws + pl.a[j], params, ws, ph + 1 >= phase_hi, st));
       } else {
         const int C = s->channels[L - 1];
         OCEAN_TRY(mean_mid(ws + pl.a[j], ws + pl.pooled, s->B, s->T, C, st));
