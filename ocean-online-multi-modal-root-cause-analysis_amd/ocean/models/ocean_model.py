@@ -94,6 +94,11 @@ class OCEANModel(nn.Module):
         self.output_activation = nn.Sigmoid()
         self.prediction_loss_weight = config.training.prediction_loss_weight
         self.contrastive_loss_weight = config.training.contrastive_loss_weight
+        # overlap_encoders: run the graph encoder on a second HIP stream next to the dilated CNN (same results).
+        # Off by default: measured on the 256-service / batch-1024 step it costs 0.5 ms (13.2 ms against 12.8) - the
+        # gather kernels take compute units and L2 from the matrix kernels for longer than they save.
+        self.overlap_encoders = False
+        self._side_streams: Dict[torch.device, Any] = {}
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -128,6 +133,12 @@ class OCEANModel(nn.Module):
             service_graph._ocean_device_graph = cache
         return cache[1], cache[2]
 
+    def _encoder_stream(self, dev: torch.device) -> "torch.cuda.Stream":
+        st = self._side_streams.get(dev)
+        if st is None:
+            st = self._side_streams[dev] = torch.cuda.Stream(dev)
+        return st
+
     def _head_params(self):
         h = self.prediction_head
         return [h[0].weight, h[0].bias, h[3].weight, h[3].bias, h[6].weight, h[6].bias]
@@ -140,10 +151,23 @@ class OCEANModel(nn.Module):
             raise _hip.OceanHipError("OCEANModel runs on an MI355X: move it with .cuda(); there is no CPU path")
         metrics = metrics.to(dev, torch.float32, non_blocking=True)
         batch_size = metrics.size(0)
-        temporal = self.temporal_encoder(metrics)
-
         graph, node_features = self.device_graph(service_graph)
-        spatial = self.spatial_encoder.forward_graph(node_features, graph, batch_size)
+        if self.overlap_encoders:
+            # The two encoders do not depend on each other.  The graph encoder's gather kernels are bound by
+            # dependent-load latency and leave the matrix pipes idle, the dilated CNN is bound by the matrix pipes:
+            # on separate streams they share the chip.  autograd runs each backward on its forward's stream, so
+            # the two backward passes overlap the same way.
+            cur = torch.cuda.current_stream(dev)
+            side = self._encoder_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                spatial = self.spatial_encoder.forward_graph(node_features, graph, batch_size)
+            temporal = self.temporal_encoder(metrics)
+            cur.wait_stream(side)
+            spatial.record_stream(cur)
+        else:
+            temporal = self.temporal_encoder(metrics)
+            spatial = self.spatial_encoder.forward_graph(node_features, graph, batch_size)
 
         if logs is None:
             log_features = torch.zeros(batch_size, self.log_input_dim, device=dev)
