@@ -116,9 +116,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # OCEAN_BENCH_DIST=1 takes the data-parallel code path (RCCL process group, collectives, eager launches) with a
+    # single rank as well: a smoke test of that path on a one-GPU box
+    use_dist = world > 1 or os.environ.get("OCEAN_BENCH_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     import ocean
     from ocean import _hip
@@ -132,41 +137,38 @@ def main():
     model = ocean.OCEANModel(cfg).to(device)
     model.contrastive_negatives = "in_batch"
     learner = OnlineLearner(model, cfg)
-    learner.use_hip_graph = world == 1 and not args.no_graph
-    if world > 1:
+    learner.use_hip_graph = not use_dist and not args.no_graph
+    if use_dist:
         from ocean.parallel import DataParallel
         DataParallel(model, learner)
     metrics, logs, nf, adj, labels = synth_inputs(B, T, N, N, rank, device)
     graph = ServiceGraph(adjacency_matrix=adj, node_features=nf)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(max(args.warmup, 3 if learner.use_hip_graph else 0)):   # the graph is recorded on the third step
         learner.process_tensors(metrics, graph, logs, labels)
     barrier()
-    _hip.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         learner.process_tensors(metrics, graph, logs, labels)
     barrier()
     dt = time.perf_counter() - t0
+    # Roofline kernel timing: the library brackets each GEMM launch with HIP events on the launch stream.  That costs
+    # host time per launch and sees nothing under HIP-graph replay, so it runs over a few eagerly launched steps after
+    # the timed region (on every rank: the steps contain the collectives).
+    prof_steps = max(3, args.steps // 4)
+    learner.use_hip_graph = False
+    _hip.profile_enable(True)
+    for _ in range(prof_steps):
+        learner.process_tensors(metrics, graph, logs, labels)
+    torch.cuda.synchronize()
     prof = _hip.profile_summary()
-    if not prof:
-        # HIP-graph replays bypass the library's launch path, so its per-launch events saw nothing: time the same
-        # kernels over a few eagerly launched steps right after the timed region
-        learner.use_hip_graph = False
-        for _ in range(max(3, args.steps // 4)):
-            learner.process_tensors(metrics, graph, logs, labels)
-        torch.cuda.synchronize()
-        prof = _hip.profile_summary()
-        prof_steps = max(3, args.steps // 4)
-    else:
-        prof_steps = args.steps
     _hip.profile_enable(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -196,7 +198,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, nf, adj, T, N)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
