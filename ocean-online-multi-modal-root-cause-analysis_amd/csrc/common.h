@@ -92,6 +92,8 @@ struct GemmP {
   int relu;
   double* colstats;         // [slots][2][N] running (sum, sum of squares) of the pre-epilogue value, atomically accumulated, or null
   int colstat_slots;        // row-tile t adds into copy t % slots (same-address atomics serialise; the caller sums the copies)
+  float* a_colsum;          // row reductions (a_kmajor) with one tap only: a_colsum[m] += sum_k A[k][m], the bias gradient of a
+                            // linear layer whose weight gradient this launch computes; or null
 };
 
 int ocean_launch_gemm(const GemmP& p, hipStream_t stream);
@@ -112,7 +114,7 @@ static inline GemmP gemm_defaults() {
   GemmP p;
   p.A = p.B = nullptr; p.C = nullptr; p.M = p.N = p.K = 0; p.lda = p.ldb = p.ldc = 0;
   p.a_kmajor = 0; p.b_kn = 0; p.taps = 1; p.T = 0; p.shift0 = 0; p.shift_step = 0;
-  p.tap_stride_b = 0; p.tap_stride_c = 0; p.split_k = 1; p.bias = nullptr; p.R = nullptr; p.ldr = 0; p.r_bcast_T = 0; p.r_scale = 1.f;
+  p.tap_stride_b = 0; p.tap_stride_c = 0; p.split_k = 1; p.bias = nullptr; p.a_colsum = nullptr; p.R = nullptr; p.ldr = 0; p.r_bcast_T = 0; p.r_scale = 1.f;
   p.relu = 0; p.colstats = nullptr; p.colstat_slots = 1;
   return p;
 }

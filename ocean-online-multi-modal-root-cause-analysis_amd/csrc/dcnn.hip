@@ -522,8 +522,7 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
     if (ph == 0) {
       OCEAN_TRY(zero_f32(wb + pl.bstats[0], pl.bwd_total - pl.bstats[0], st));   // bstats + packed weight grads
       // output projection
-      OCEAN_TRY(linear_bwd_weight(dout, s->out_dim, wf + pl.pooled, Cl, grads[pi_out(L, 0)], s->B, s->out_dim, Cl, st));
-      OCEAN_TRY(colsum_add(dout, s->out_dim, s->B, s->out_dim, grads[pi_out(L, 1)], st));
+      OCEAN_TRY(linear_bwd_weight(dout, s->out_dim, wf + pl.pooled, Cl, grads[pi_out(L, 0)], s->B, s->out_dim, Cl, st, grads[pi_out(L, 1)]));   // + bias gradient (column sums of the same operand)
       OCEAN_TRY(linear_bwd_data(dout, s->out_dim, params[pi_out(L, 0)], wb + pl.dpool, Cl, s->B, s->out_dim, Cl, 0, st));
       OCEAN_TRY(reduce(pl.nbn - 1));
       continue;
@@ -578,8 +577,7 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
       // input projection: grad wrt h0 sits in grad_buf(0)
       const float* dh0 = grad_buf(0);
       const int C0 = s->channels[0];
-      OCEAN_TRY(linear_bwd_weight(dh0, C0, x, s->F, grads[0], M, C0, s->F, st));
-      OCEAN_TRY(colsum_add(dh0, C0, M, C0, grads[1], st));
+      OCEAN_TRY(linear_bwd_weight(dh0, C0, x, s->F, grads[0], M, C0, s->F, st, grads[1]));   // + bias gradient (column sums of the same operand)
       if (dx) OCEAN_TRY(linear_bwd_data(dh0, C0, params[0], dx, s->F, M, C0, s->F, 0, st));
     }
   }

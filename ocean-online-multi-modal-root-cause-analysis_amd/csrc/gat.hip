@@ -1293,8 +1293,7 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
   const long rows = pl.rows;
   const int Cl = pl.out_dim[Lr - 1];
   // output projection
-  OCEAN_TRY(linear_bwd_weight(dout, D, wf + pl.pooled, Cl, grads[pg_out(Lr, 0)], pl.P, D, Cl, st));
-  OCEAN_TRY(colsum_add(dout, D, pl.P, D, grads[pg_out(Lr, 1)], st));
+  OCEAN_TRY(linear_bwd_weight(dout, D, wf + pl.pooled, Cl, grads[pg_out(Lr, 0)], pl.P, D, Cl, st, grads[pg_out(Lr, 1)]));   // + bias gradient (column sums of the same operand)
   OCEAN_TRY(linear_bwd_data(dout, D, params[pg_out(Lr, 0)], wb + pl.dpool, Cl, pl.P, D, Cl, 0, st));
   const bool share0 = s->R > 1 && fast_edges(pl);
   float* dx0 = wb + pl.dx0;
@@ -1404,8 +1403,7 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
     OCEAN_TRY(copy2d(dx0, D, wb + pl.dY, D, s->N, D, 0, st));
   }
   OCEAN_TRY(relu_bwd_inplace(dx0, D, wf + pl.x0, D, s->N, D, st));
-  OCEAN_TRY(linear_bwd_weight(dx0, D, node_features, s->G, grads[0], s->N, D, s->G, st));
-  OCEAN_TRY(colsum_add(dx0, D, s->N, D, grads[1], st));
+  OCEAN_TRY(linear_bwd_weight(dx0, D, node_features, s->G, grads[0], s->N, D, s->G, st, grads[1]));   // + bias gradient (column sums of the same operand)
   return OCEAN_OK;
 }
 

@@ -334,9 +334,17 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
   // LDS address of the body is a lane-constant base plus an immediate offset: no vector instruction is spent on
   // ring pointers.  Vector instructions take issue slots from the MFMAs of the same SIMD: measured, 24 extra
   // v_add per tile cost 3 % of the C = 512 convolutions' rate.
+  // Row reductions can deliver the column sums of A on the side (a linear layer's bias gradient next to its weight
+  // gradient): the blocks of the first tile column add up the A tile they stage anyway, one thread per column.
+  const bool colsum_on = AKM && p.a_colsum != nullptr && tile_n == 0 && ztap == 0 && tid < BM;
+  float a_csum = 0.f;
   auto tile_step = [&](auto slot, const int it) {
     constexpr int buf = decltype(slot)::value;
     constexpr int nbuf = (buf + 1 == kRing) ? 0 : buf + 1;
+    if (AKM && colsum_on) {      // slot `buf` holds tile `it` (zero beyond the reduction range) until the next barrier
+#pragma unroll
+      for (int kk = 0; kk < BK; ++kk) a_csum += As[(buf * BK + kk) * LDA + tid];
+    }
     const float* Ac = As + buf * BK * LDA + a_frag;
     const float* Bc = Bs + buf * BK * LDB + b_frag;
     const float* An = As + nbuf * BK * LDA + a_frag;
@@ -391,6 +399,8 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
     tile_step(std::integral_constant<int, 0>{}, it);
     if (it + 1 < n_iter) tile_step(std::integral_constant<int, 1>{}, it + 1);
   }
+
+  if (AKM && colsum_on && m0 + tid < p.M) unsafeAtomicAdd(p.a_colsum + m0 + tid, a_csum);
 
   // ------------------------------------------------------------ epilogue
   // acc register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile.

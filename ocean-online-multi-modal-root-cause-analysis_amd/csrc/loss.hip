@@ -303,18 +303,15 @@ int ocean_head_bwd(const ocean_head_shape* s, const float* x, float* const* P_, 
   float* dl = wb; float* d1 = wb + al4((size_t)B * s->S); float* d2 = d1 + al4((size_t)B * s->h1);
   hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(egrid((long)B * s->S)), dim3(256), 0, st, dlogits, dprobs, probs, dl, (long)B * s->S);
   OCEAN_LAUNCH_CHECK();
-  OCEAN_TRY(linear_bwd_weight(dl, s->S, a2, s->h2, G_[4], B, s->S, s->h2, st));
-  OCEAN_TRY(colsum_add(dl, s->S, B, s->S, G_[5], st));
+  OCEAN_TRY(linear_bwd_weight(dl, s->S, a2, s->h2, G_[4], B, s->S, s->h2, st, G_[5]));   // + bias gradient (column sums of the same operand)
   OCEAN_TRY(linear_bwd_data(dl, s->S, P_[4], d2, s->h2, B, s->S, s->h2, 0, st));
   OCEAN_TRY(dropout_inplace(d2, s->h2, B, s->h2, 1, head_site(s, 1), st));
   OCEAN_TRY(relu_bwd_inplace(d2, s->h2, a2, s->h2, B, s->h2, st));
-  OCEAN_TRY(linear_bwd_weight(d2, s->h2, a1, s->h1, G_[2], B, s->h2, s->h1, st));
-  OCEAN_TRY(colsum_add(d2, s->h2, B, s->h2, G_[3], st));
+  OCEAN_TRY(linear_bwd_weight(d2, s->h2, a1, s->h1, G_[2], B, s->h2, s->h1, st, G_[3]));   // + bias gradient (column sums of the same operand)
   OCEAN_TRY(linear_bwd_data(d2, s->h2, P_[2], d1, s->h1, B, s->h2, s->h1, 0, st));
   OCEAN_TRY(dropout_inplace(d1, s->h1, B, s->h1, 1, head_site(s, 0), st));
   OCEAN_TRY(relu_bwd_inplace(d1, s->h1, a1, s->h1, B, s->h1, st));
-  OCEAN_TRY(linear_bwd_weight(d1, s->h1, x, s->E, G_[0], B, s->h1, s->E, st));
-  OCEAN_TRY(colsum_add(d1, s->h1, B, s->h1, G_[1], st));
+  OCEAN_TRY(linear_bwd_weight(d1, s->h1, x, s->E, G_[0], B, s->h1, s->E, st, G_[1]));   // + bias gradient (column sums of the same operand)
   if (dx) OCEAN_TRY(linear_bwd_data(d1, s->h1, P_[0], dx, s->E, B, s->h1, s->E, 0, st));
   return OCEAN_OK;
 }

@@ -10,7 +10,7 @@ int linear_bwd_data(const float* dy, int lddy, const float* W, float* dx, int ld
                     int M, int N, int K, int accumulate, hipStream_t s);
 // dW[N,K] += dy[M,N]^T . x[M,K]                          (nn.Linear weight gradient, atomic accumulate)
 int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float* dW,
-                      int M, int N, int K, hipStream_t s);
+                      int M, int N, int K, hipStream_t s, float* db = nullptr);
 // Batched forms: up to kGemmBatchMax independent layers (the three modality branches) per launch.
 struct LinFwd { const float* x; int ldx; const float* W; const float* b; float* y; int ldy; int M, N, K; };
 int linear_fwd_batch(const LinFwd* l, int n, int relu, hipStream_t s);

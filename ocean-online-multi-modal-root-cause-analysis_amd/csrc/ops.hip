@@ -21,8 +21,9 @@ int linear_bwd_data(const float* dy, int lddy, const float* W, float* dx, int ld
 }
 
 int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float* dW,
-                      int M, int N, int K, hipStream_t s) {
+                      int M, int N, int K, hipStream_t s, float* db) {
   GemmP p = gemm_defaults();
+  p.a_colsum = db;
   p.A = dy; p.lda = lddy; p.a_kmajor = 1; p.B = x; p.ldb = ldx; p.b_kn = 1; p.C = dW; p.ldc = K;
   p.M = N; p.N = K; p.K = M; p.split_k = 0;
   return ocean_launch_gemm(p, s);
@@ -48,13 +49,14 @@ int linear_bwd_batch(const LinBwd* l, int n, int accumulate_dx, hipStream_t s) {
     g[k] = gemm_defaults();
     g[k].A = l[q].dy; g[k].lda = l[q].lddy; g[k].a_kmajor = 1; g[k].B = l[q].x; g[k].ldb = l[q].ldx; g[k].b_kn = 1;
     g[k].C = l[q].dW; g[k].ldc = l[q].K; g[k].M = l[q].N; g[k].N = l[q].K; g[k].K = l[q].M; g[k].split_k = 0;
+    g[k].a_colsum = l[q].db;       // the bias gradient rides along with the weight gradient
     ++k;
   }
   if (k > 0) OCEAN_TRY(ocean_launch_gemm_batch(g, k, s));
   ColSum c[kGemmBatchMax];
   k = 0;
   for (int q = 0; q < n; ++q) {
-    if (!l[q].db) continue;
+    if (!l[q].db || l[q].dW) continue;
     c[k].a = l[q].dy; c[k].lda = l[q].lddy; c[k].M = l[q].M; c[k].N = l[q].N; c[k].out = l[q].db;
     ++k;
   }
