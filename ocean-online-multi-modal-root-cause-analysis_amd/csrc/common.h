@@ -92,6 +92,12 @@ struct GemmP {
   int relu;
   double* colstats;         // [slots][2][N] running (sum, sum of squares) of the pre-epilogue value, atomically accumulated, or null
   int colstat_slots;        // row-tile t adds into copy t % slots (same-address atomics serialise; the caller sums the copies)
+  // epilogue of non-reducing launches, applied after bias / residual / ReLU:
+  DropoutP drop;            // p > 0: out *= keep(index); index = (drop_row0 + row) * (N / drop_group) + col / drop_group, the
+  int drop_group;           // numbering dropout_inplace uses on the [rows, N] matrix this output is a row block of
+  int drop_row0;
+  const float* relu_mask;   // non-null: out = relu_mask[row * ld_mask + col] > 0 ? out : 0   (ReLU backward on a saved output)
+  int ld_mask;
   float* a_colsum;          // row reductions (a_kmajor) with one tap only: a_colsum[m] += sum_k A[k][m], the bias gradient of a
                             // linear layer whose weight gradient this launch computes; or null
 };
@@ -114,7 +120,8 @@ static inline GemmP gemm_defaults() {
   GemmP p;
   p.A = p.B = nullptr; p.C = nullptr; p.M = p.N = p.K = 0; p.lda = p.ldb = p.ldc = 0;
   p.a_kmajor = 0; p.b_kn = 0; p.taps = 1; p.T = 0; p.shift0 = 0; p.shift_step = 0;
-  p.tap_stride_b = 0; p.tap_stride_c = 0; p.split_k = 1; p.bias = nullptr; p.a_colsum = nullptr; p.R = nullptr; p.ldr = 0; p.r_bcast_T = 0; p.r_scale = 1.f;
+  p.tap_stride_b = 0; p.tap_stride_c = 0; p.split_k = 1; p.bias = nullptr; p.a_colsum = nullptr; p.drop = DropoutP{0.f, 0, nullptr}; p.drop_group = 1; p.drop_row0 = 0;
+  p.relu_mask = nullptr; p.ld_mask = 0; p.R = nullptr; p.ldr = 0; p.r_bcast_T = 0; p.r_scale = 1.f;
   p.relu = 0; p.colstats = nullptr; p.colstat_slots = 1;
   return p;
 }

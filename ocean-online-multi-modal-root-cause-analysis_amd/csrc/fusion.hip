@@ -146,10 +146,10 @@ DropoutP site(const ocean_fusion_shape* s, int id) {
 }
 
 int lin_bwd(const float* x, int ldx, const float* dy, int lddy, int M, int N, int K, const float* W, float* dW, float* db,
-            float* dx, int lddx, int accumulate, hipStream_t st) {
+            float* dx, int lddx, int accumulate, hipStream_t st, const Epi* dx_epi = nullptr) {
   if (dW) OCEAN_TRY(linear_bwd_weight(dy, lddy, x, ldx, dW, M, N, K, st, db));   // db rides along as the column sums of dy
   else if (db) OCEAN_TRY(colsum_add(dy, lddy, M, N, db, st));
-  if (dx) OCEAN_TRY(linear_bwd_data(dy, lddy, W, dx, lddx, M, N, K, accumulate, st));
+  if (dx) OCEAN_TRY(linear_bwd_data(dy, lddy, W, dx, lddx, M, N, K, accumulate, st, dx_epi));
   return OCEAN_OK;
 }
 
@@ -183,8 +183,8 @@ int ocean_fusion_fwd(const ocean_fusion_shape* s, const float* t, const float* s
   OCEAN_TRY(layernorm_fwd_batch(ln, 3, E, 3 * E, B, E, s->eps, site(s, 0), st));
   if (s->contrastive) {
     for (int m = 0; m < 3; ++m) l[m] = LinFwd{X + m * E, 3 * E, P_[22 + 4 * m], P_[23 + 4 * m], ws + pl.Y1 + m * BE, E, B, E, E};
-    OCEAN_TRY(linear_fwd_batch(l, 3, 1, st));
-    OCEAN_TRY(dropout_inplace(ws + pl.Y1, E, 3 * B, E, 1, site(s, 5), st));
+    const DropoutP d5 = site(s, 5);
+    OCEAN_TRY(linear_fwd_batch(l, 3, 1, st, &d5, 1));
     for (int m = 0; m < 3; ++m)
       l[m] = LinFwd{ws + pl.Y1 + m * BE, E, P_[24 + 4 * m], P_[25 + 4 * m], ws + pl.Y2 + (size_t)m * B * Pd, Pd, B, Pd, E};
     OCEAN_TRY(linear_fwd_batch(l, 3, 0, st));
@@ -197,8 +197,9 @@ int ocean_fusion_fwd(const ocean_fusion_shape* s, const float* t, const float* s
   OCEAN_TRY(mean_mid(ws + pl.O, ws + pl.Om, B, kTok, E, st));
   OCEAN_TRY(linear_fwd(ws + pl.Om, E, P_[14], P_[15], ws + pl.Ao, E, B, E, E, 0, st));
   OCEAN_TRY(layernorm_fwd(ws + pl.Ao, E, P_[16], P_[17], ws + pl.Fn, E, ws + pl.lnsa, B, E, s->eps, none, st));
-  OCEAN_TRY(linear_fwd(ws + pl.Fn, E, P_[18], P_[19], ws + pl.H1, E, B, E, E, 1, st));
-  OCEAN_TRY(dropout_inplace(ws + pl.H1, E, B, E, 1, site(s, 4), st));
+  const DropoutP d4 = site(s, 4);
+  Epi e4; e4.drop = &d4;
+  OCEAN_TRY(linear_fwd(ws + pl.Fn, E, P_[18], P_[19], ws + pl.H1, E, B, E, E, 1, st, &e4));
   OCEAN_TRY(linear_fwd(ws + pl.H1, E, P_[20], P_[21], fused, E, B, E, E, 0, st));
   return OCEAN_OK;
 }
@@ -216,9 +217,9 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* s
   const DropoutP none = {0.f, 0, nullptr};
   float* e1 = wb + pl.e1; float* e2 = wb + pl.e2; float* dX = wb + pl.dX;
   if (dfused) {
-    OCEAN_TRY(lin_bwd(wf + pl.H1, E, dfused, E, B, E, E, P_[20], G_[20], G_[21], e2, E, 0, st));
-    OCEAN_TRY(dropout_inplace(e2, E, B, E, 1, site(s, 4), st));
-    OCEAN_TRY(relu_bwd_inplace(e2, E, wf + pl.H1, E, B, E, st));
+    const DropoutP d4 = site(s, 4);
+    Epi e4; e4.drop = &d4; e4.relu_mask = wf + pl.H1; e4.ld_mask = E;   // dropout and ReLU backward on the way out of the dgrad GEMM
+    OCEAN_TRY(lin_bwd(wf + pl.H1, E, dfused, E, B, E, E, P_[20], G_[20], G_[21], e2, E, 0, st, &e4));
     OCEAN_TRY(lin_bwd(wf + pl.Fn, E, e2, E, B, E, E, P_[18], G_[18], G_[19], e1, E, 0, st));
     OCEAN_TRY(layernorm_bwd(e1, E, wf + pl.Ao, E, wf + pl.lnsa, P_[16], e1, E, G_[16], G_[17], B, E, none, st));
     OCEAN_TRY(lin_bwd(wf + pl.Om, E, e1, E, B, E, E, P_[14], G_[14], G_[15], wb + pl.dOm, E, 0, st));
@@ -237,9 +238,9 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* s
     for (int m = 0; m < 3; ++m)
       l[m] = LinBwd{wf + pl.Y1 + m * BE, E, wb + pl.dY2 + (size_t)m * B * Pd, Pd, B, Pd, E, P_[24 + 4 * m], G_[24 + 4 * m], G_[25 + 4 * m],
                     wb + pl.dY1 + m * BE, E};
-    OCEAN_TRY(linear_bwd_batch(l, 3, 0, st));
-    OCEAN_TRY(dropout_inplace(wb + pl.dY1, E, 3 * B, E, 1, site(s, 5), st));
-    OCEAN_TRY(relu_bwd_inplace(wb + pl.dY1, E, wf + pl.Y1, E, 3 * B, E, st));
+    const DropoutP d5 = site(s, 5);
+    const float* y1[3] = {wf + pl.Y1, wf + pl.Y1 + BE, wf + pl.Y1 + 2 * BE};
+    OCEAN_TRY(linear_bwd_batch(l, 3, 0, st, &d5, 1, y1, E));
     for (int m = 0; m < 3; ++m)
       l[m] = LinBwd{X + m * E, 3 * E, wb + pl.dY1 + m * BE, E, B, E, E, P_[22 + 4 * m], G_[22 + 4 * m], G_[23 + 4 * m], dX + m * E, 3 * E};
     OCEAN_TRY(linear_bwd_batch(l, 3, 1, st));

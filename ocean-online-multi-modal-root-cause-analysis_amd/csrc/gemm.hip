@@ -403,14 +403,29 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
   if (AKM && colsum_on && m0 + tid < p.M) unsafeAtomicAdd(p.a_colsum + m0 + tid, a_csum);
 
   // ------------------------------------------------------------ epilogue
+  // Every field the epilogue reads is copied into a local first: `p` lives in the kernel-argument segment and the
+  // compiler re-reads fields from it after each global store (it cannot prove the stores do not alias), which put
+  // hundreds of dependent scalar loads and waits into the unrolled element loop.
+  struct {
+    float* C; int M, N; const float* R; const float* bias; int colstat_slots; double* colstats; DropoutP drop;
+    int drop_group, drop_row0, ld_mask, ldc, ldr, r_bcast_T; float r_scale; int relu; const float* relu_mask; long tap_stride_c;
+  } e = {p.C, p.M, p.N, p.R, p.bias, p.colstat_slots, p.colstats, p.drop, p.drop_group, p.drop_row0, p.ld_mask, p.ldc, p.ldr,
+         p.r_bcast_T, p.r_scale, p.relu, p.relu_mask, (long)p.tap_stride_c};
   // acc register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile.
-  float* Cz = p.C + (AKM ? (long)ztap * p.tap_stride_c : 0);
+  float* Cz = e.C + (AKM ? (long)ztap * e.tap_stride_c : 0);
+  const DropoutP drop = dropout_resolve(e.drop);
+  const int drop_group = e.drop_group;
   const bool atomic_out = AKM;   // row-reduction outputs always accumulate (C += ...)
+  // The output dropout / ReLU-mask options get an epilogue instance of their own, chosen by a block-uniform test:
+  // with the tests inside the element loop every store of the common case sat behind two extra branches, which
+  // cost the short-reduction convolutions 5-20 %.
+  auto epilogue = [&](auto extra_c) {
+  constexpr bool EXTRA = decltype(extra_c)::value;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-    const bool col_ok = col < p.N;
-    if (p.colstats != nullptr) {
+    const bool col_ok = col < e.N;
+    if (e.colstats != nullptr) {
       float s = 0.f, q = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -419,12 +434,12 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
       s += __shfl_xor(s, 32);
       q += __shfl_xor(q, 32);
       if (lane < 32 && col_ok) {
-        double* cs = p.colstats + (size_t)(tile_m % p.colstat_slots) * 2 * p.N;
+        double* cs = e.colstats + (size_t)(tile_m % e.colstat_slots) * 2 * e.N;
         unsafeAtomicAdd(cs + col, (double)s);
-        unsafeAtomicAdd(cs + p.N + col, (double)q);
+        unsafeAtomicAdd(cs + e.N + col, (double)q);
       }
     }
-    const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+    const float bias = (e.bias != nullptr && col_ok) ? e.bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * khalf;
@@ -433,20 +448,20 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         float rv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!atomic_out && p.R != nullptr) {
-          if (p.r_bcast_T > 0) {
+        if (!atomic_out && e.R != nullptr) {
+          if (e.r_bcast_T > 0) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
               const int row = row_base + r4 + 8 * rq;
-              const bool ok = row < p.M && col_ok;
-              rv[r4] = p.r_scale * p.R[ok ? (long)(row / p.r_bcast_T) * p.ldr + col : 0];
+              const bool ok = row < e.M && col_ok;
+              rv[r4] = e.r_scale * e.R[ok ? (long)(row / e.r_bcast_T) * e.ldr + col : 0];
             }
           } else {
-            const float* rp = p.R + (long)(row_base + 8 * rq) * p.ldr + col;
+            const float* rp = e.R + (long)(row_base + 8 * rq) * e.ldr + col;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-              const bool ok = row_base + 8 * rq + r4 < p.M && col_ok;
-              rv[r4] = ok ? rp[(long)r4 * p.ldr] : 0.f;
+              const bool ok = row_base + 8 * rq + r4 < e.M && col_ok;
+              rv[r4] = ok ? rp[(long)r4 * e.ldr] : 0.f;
             }
           }
         }
@@ -454,20 +469,91 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
         for (int r4 = 0; r4 < 4; ++r4) {
           const int r = rq * 4 + r4;
           const int row = row_base + r4 + 8 * rq;
-          if (row < p.M && col_ok) {
+          if (row < e.M && col_ok) {
             float v = acc[i][j][r] + bias;
             if (atomic_out) {
-              unsafeAtomicAdd(Cz + (long)row * p.ldc + col, v);
+              unsafeAtomicAdd(Cz + (long)row * e.ldc + col, v);
             } else {
               v += rv[r4];
-              if (p.relu) v = fmaxf(v, 0.f);
-              Cz[(long)row * p.ldc + col] = v;
+              if (e.relu) v = fmaxf(v, 0.f);
+              if (EXTRA) {
+                if (drop.p > 0.f) {
+                  const uint64_t di = drop_group > 1 ? (uint64_t)(e.drop_row0 + row) * (e.N / drop_group) + col / drop_group
+                                                     : (uint64_t)(e.drop_row0 + row) * e.N + col;
+                  v *= dropout_keep(drop, di);
+                }
+                if (e.relu_mask != nullptr && !(e.relu_mask[(long)row * e.ld_mask + col] > 0.f)) v = 0.f;
+              }
+              Cz[(long)row * e.ldc + col] = v;
             }
           }
         }
       }
     }
   }
+  };
+  // Blocks whose whole tile lies inside C (all of them for the encoder convolutions) skip every bounds test and
+  // address each element as a wave-uniform row pointer (scalar registers, advanced by scalar adds) plus one
+  // lane-constant 32-bit offset, so an element costs its arithmetic and one store and nothing else.
+  auto epilogue_full = [&]() {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int row_w = m0 + (wave_u / WN) * (BM / 2), col_w = n0 + (wave_u % WN) * (BN / 2);
+    const int lcol = lane & 31;
+    // byte offsets of this lane inside any 8-row group (they fit 32 bits: a tile spans at most BM rows)
+    const uint32_t c_lane = ((uint32_t)(4 * khalf) * (uint32_t)e.ldc + lcol) * 4u;
+    const uint32_t r_lane = ((uint32_t)(4 * khalf) * (uint32_t)e.ldr + lcol) * 4u;
+    const bool has_r = !atomic_out && e.R != nullptr;
+    const float floor_v = e.relu ? 0.f : -__builtin_inff();
+    const char* r_w = (const char*)(e.R + (has_r ? (long)row_w * e.ldr + col_w : 0));
+    char* c_w = (char*)(Cz + (long)row_w * e.ldc + col_w);
+    const uint32_t c_pitch = (uint32_t)e.ldc * 4u, r_pitch = (uint32_t)e.ldr * 4u;
+    // buffer instructions take the wave-uniform part of the address as a scalar offset operand
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(c_w, 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(r_w), 0, 0x7FFFFFF0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col_u = col_w + j * 32;
+      if (e.colstats != nullptr) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s += v; q += v * v; }
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (lane < 32) {
+          double* cs = e.colstats + (size_t)(tile_m % e.colstat_slots) * 2 * e.N + col_u;
+          unsafeAtomicAdd(cs + lcol, (double)s);
+          unsafeAtomicAdd(cs + e.N + lcol, (double)q);
+        }
+      }
+      const float bias = e.bias != nullptr ? e.bias[col_u + lcol] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        // the sixteen residual values of a 32x32 sub-tile are requested together: one memory round trip, not four
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+        if (has_r) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                rs_r, (int)r_lane, (int)((uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3)) * r_pitch + (uint32_t)(j * 128)), 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t c_soff = (uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3)) * c_pitch + (uint32_t)(j * 128);
+          const float v = acc[i][j][r] + bias;
+          if (atomic_out) unsafeAtomicAdd((float*)(c_w + (size_t)c_soff + c_lane), v);
+          else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(v + rv[r], floor_v)), rs_c, (int)c_lane, (int)c_soff, 0);
+        }
+      }
+    }
+  };
+  const bool extra = !AKM && (drop.p > 0.f || e.relu_mask != nullptr);
+  if (extra) epilogue(std::true_type{});
+  else if (m0 + BM <= e.M && n0 + BN <= e.N && e.r_bcast_T <= 0) epilogue_full();
+  else epilogue(std::false_type{});
 }
 
 template <int BM, int BN, int BK, bool AKM, bool BKN>

@@ -283,10 +283,10 @@ int ocean_head_fwd(const ocean_head_shape* s, const float* x, float* const* P_, 
   if (ws_floats < ocean_head_workspace(s)) return OCEAN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   float* a1 = ws; float* a2 = ws + al4((size_t)s->B * s->h1);
-  OCEAN_TRY(linear_fwd(x, s->E, P_[0], P_[1], a1, s->h1, s->B, s->h1, s->E, 1, st));
-  OCEAN_TRY(dropout_inplace(a1, s->h1, s->B, s->h1, 1, head_site(s, 0), st));
-  OCEAN_TRY(linear_fwd(a1, s->h1, P_[2], P_[3], a2, s->h2, s->B, s->h2, s->h1, 1, st));
-  OCEAN_TRY(dropout_inplace(a2, s->h2, s->B, s->h2, 1, head_site(s, 1), st));
+  const DropoutP dr0 = head_site(s, 0), dr1 = head_site(s, 1);   // dropout rides in the epilogue of the producing GEMM
+  Epi e0, e1; e0.drop = &dr0; e1.drop = &dr1;
+  OCEAN_TRY(linear_fwd(x, s->E, P_[0], P_[1], a1, s->h1, s->B, s->h1, s->E, 1, st, &e0));
+  OCEAN_TRY(linear_fwd(a1, s->h1, P_[2], P_[3], a2, s->h2, s->B, s->h2, s->h1, 1, st, &e1));
   OCEAN_TRY(linear_fwd(a2, s->h2, P_[4], P_[5], logits, s->S, s->B, s->S, s->h2, 0, st));
   hipLaunchKernelGGL(sigmoid_kernel, dim3(egrid((long)s->B * s->S)), dim3(256), 0, st, logits, probs, (long)s->B * s->S);
   OCEAN_LAUNCH_CHECK();
@@ -304,13 +304,13 @@ int ocean_head_bwd(const ocean_head_shape* s, const float* x, float* const* P_, 
   hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(egrid((long)B * s->S)), dim3(256), 0, st, dlogits, dprobs, probs, dl, (long)B * s->S);
   OCEAN_LAUNCH_CHECK();
   OCEAN_TRY(linear_bwd_weight(dl, s->S, a2, s->h2, G_[4], B, s->S, s->h2, st, G_[5]));   // + bias gradient (column sums of the same operand)
-  OCEAN_TRY(linear_bwd_data(dl, s->S, P_[4], d2, s->h2, B, s->S, s->h2, 0, st));
-  OCEAN_TRY(dropout_inplace(d2, s->h2, B, s->h2, 1, head_site(s, 1), st));
-  OCEAN_TRY(relu_bwd_inplace(d2, s->h2, a2, s->h2, B, s->h2, st));
+  const DropoutP dr0 = head_site(s, 0), dr1 = head_site(s, 1);
+  Epi e0, e1;      // dropout and ReLU backward on the way out of the dgrad GEMMs
+  e0.drop = &dr0; e0.relu_mask = a1; e0.ld_mask = s->h1;
+  e1.drop = &dr1; e1.relu_mask = a2; e1.ld_mask = s->h2;
+  OCEAN_TRY(linear_bwd_data(dl, s->S, P_[4], d2, s->h2, B, s->S, s->h2, 0, st, &e1));
   OCEAN_TRY(linear_bwd_weight(d2, s->h2, a1, s->h1, G_[2], B, s->h2, s->h1, st, G_[3]));   // + bias gradient (column sums of the same operand)
-  OCEAN_TRY(linear_bwd_data(d2, s->h2, P_[2], d1, s->h1, B, s->h2, s->h1, 0, st));
-  OCEAN_TRY(dropout_inplace(d1, s->h1, B, s->h1, 1, head_site(s, 0), st));
-  OCEAN_TRY(relu_bwd_inplace(d1, s->h1, a1, s->h1, B, s->h1, st));
+  OCEAN_TRY(linear_bwd_data(d2, s->h2, P_[2], d1, s->h1, B, s->h2, s->h1, 0, st, &e0));
   OCEAN_TRY(linear_bwd_weight(d1, s->h1, x, s->E, G_[0], B, s->h1, s->E, st, G_[1]));   // + bias gradient (column sums of the same operand)
   if (dx) OCEAN_TRY(linear_bwd_data(d1, s->h1, P_[0], dx, s->E, B, s->h1, s->E, 0, st));
   return OCEAN_OK;

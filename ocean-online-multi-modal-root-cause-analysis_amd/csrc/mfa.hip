@@ -186,10 +186,10 @@ DropoutP site(const ocean_mfa_shape* s, int id) {
 
 // weight + bias gradients and (optionally) the data gradient of y = x W^T + b
 int lin_bwd(const float* x, int ldx, const float* dy, int lddy, int M, int N, int K, const float* W, float* dW, float* db,
-            float* dx, int lddx, int accumulate, hipStream_t st) {
+            float* dx, int lddx, int accumulate, hipStream_t st, const Epi* dx_epi = nullptr) {
   if (dW) OCEAN_TRY(linear_bwd_weight(dy, lddy, x, ldx, dW, M, N, K, st, db));   // db rides along as the column sums of dy
   else if (db) OCEAN_TRY(colsum_add(dy, lddy, M, N, db, st));
-  if (dx) OCEAN_TRY(linear_bwd_data(dy, lddy, W, dx, lddx, M, N, K, accumulate, st));
+  if (dx) OCEAN_TRY(linear_bwd_data(dy, lddy, W, dx, lddx, M, N, K, accumulate, st, dx_epi));
   return OCEAN_OK;
 }
 
@@ -217,15 +217,14 @@ int ocean_mfa_fwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
   for (int m = 0; m < 3; ++m) l[m] = LinFwd{xin[m], xd[m], P_[2 * m], P_[2 * m + 1], ws + pl.P + m * BW, W, B, W, xd[m]};
   OCEAN_TRY(linear_fwd_batch(l, 3, 0, st));
   for (int m = 0; m < 3; ++m) l[m] = LinFwd{ws + pl.P + m * BW, W, P_[6 + 4 * m], P_[7 + 4 * m], ws + pl.V + m * BW, W, B, W, W};
-  OCEAN_TRY(linear_fwd_batch(l, 3, 0, st));
-  OCEAN_TRY(dropout_inplace(ws + pl.V, W, 3 * B, W, W / s->heads, site(s, 0), st));
+  const DropoutP d0 = site(s, 0), d6 = site(s, 6);   // dropout rides in the epilogue of the GEMM that produces the tensor
+  OCEAN_TRY(linear_fwd_batch(l, 3, 0, st, &d0, W / s->heads));
   for (int m = 0; m < 3; ++m) l[m] = LinFwd{ws + pl.V + m * BW, W, P_[8 + 4 * m], P_[9 + 4 * m], ws + pl.A + m * BW, W, B, W, W};
   OCEAN_TRY(linear_fwd_batch(l, 3, 0, st));
-  OCEAN_TRY(dropout_inplace(ws + pl.A, W, 3 * B, W, 1, site(s, 3), st));
   LnFwdSet ln[3];
   for (int m = 0; m < 3; ++m)
     ln[m] = LnFwdSet{ws + pl.A + m * BW, P_[18 + 2 * m], P_[19 + 2 * m], ws + pl.Nn + m * BW, ws + pl.lnst + (size_t)m * 2 * B};
-  OCEAN_TRY(layernorm_fwd_batch(ln, 3, W, W, B, W, s->eps, none, st));
+  OCEAN_TRY(layernorm_fwd_batch(ln, 3, W, W, B, W, s->eps, site(s, 3), st));   // A stays as computed; the LayerNorm drops its input
   hipLaunchKernelGGL(cross_fwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.Nn, P_[26], ws + pl.G, ws + pl.cw, B, W);
   OCEAN_LAUNCH_CHECK();
   OCEAN_TRY(linear_fwd(ws + pl.G, W, P_[27], P_[28], ws + pl.Hd, Wh, 3 * B, Wh, W, 1, st));
@@ -233,8 +232,8 @@ int ocean_mfa_fwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
                      ws + pl.cat, B, W, Wh);
   OCEAN_LAUNCH_CHECK();
   OCEAN_TRY(linear_fwd(ws + pl.cat, 3 * W, P_[31], P_[32], ws + pl.F, W, B, W, 3 * W, 0, st));
-  OCEAN_TRY(linear_fwd(ws + pl.F, W, P_[33], P_[34], ws + pl.O1, W, B, W, W, 1, st));
-  OCEAN_TRY(dropout_inplace(ws + pl.O1, W, B, W, 1, site(s, 6), st));
+  Epi e6; e6.drop = &d6;
+  OCEAN_TRY(linear_fwd(ws + pl.F, W, P_[33], P_[34], ws + pl.O1, W, B, W, W, 1, st, &e6));
   OCEAN_TRY(linear_fwd(ws + pl.O1, W, P_[35], P_[36], ws + pl.O2, W, B, W, W, 0, st));
   OCEAN_TRY(layernorm_fwd(ws + pl.O2, W, P_[24], P_[25], out, W, ws + pl.lnso, B, W, s->eps, none, st));
   return OCEAN_OK;
@@ -253,9 +252,9 @@ int ocean_mfa_bwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
   float* e1 = wb + pl.e1; float* e2 = wb + pl.e2; float* d1 = wb + pl.d1; float* d2 = wb + pl.d2;
   // output LayerNorm and MLP
   OCEAN_TRY(layernorm_bwd(dout, W, wf + pl.O2, W, wf + pl.lnso, P_[24], e1, W, G_[24], G_[25], B, W, none, st));
-  OCEAN_TRY(lin_bwd(wf + pl.O1, W, e1, W, B, W, W, P_[35], G_[35], G_[36], e2, W, 0, st));
-  OCEAN_TRY(dropout_inplace(e2, W, B, W, 1, site(s, 6), st));
-  OCEAN_TRY(relu_bwd_inplace(e2, W, wf + pl.O1, W, B, W, st));
+  const DropoutP d0 = site(s, 0), d6 = site(s, 6);
+  Epi e6; e6.drop = &d6; e6.relu_mask = wf + pl.O1; e6.ld_mask = W;     // dropout and ReLU backward on the way out of the dgrad GEMM
+  OCEAN_TRY(lin_bwd(wf + pl.O1, W, e1, W, B, W, W, P_[35], G_[35], G_[36], e2, W, 0, st, &e6));
   OCEAN_TRY(lin_bwd(wf + pl.F, W, e2, W, B, W, W, P_[33], G_[33], G_[34], e1, W, 0, st));
   OCEAN_TRY(lin_bwd(wf + pl.cat, 3 * W, e1, W, B, W, 3 * W, P_[31], G_[31], G_[32], wb + pl.dcat, 3 * W, 0, st));
   // feature gate
@@ -277,13 +276,11 @@ int ocean_mfa_bwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
   for (int m = 0; m < 3; ++m)
     ln[m] = LnBwdSet{d2 + m * BW, wf + pl.A + m * BW, wf + pl.lnst + (size_t)m * 2 * B, P_[18 + 2 * m], d2 + m * BW, G_[18 + 2 * m],
                      G_[19 + 2 * m]};
-  OCEAN_TRY(layernorm_bwd_batch(ln, 3, W, W, W, B, W, none, st));
-  OCEAN_TRY(dropout_inplace(d2, W, 3 * B, W, 1, site(s, 3), st));
+  OCEAN_TRY(layernorm_bwd_batch(ln, 3, W, W, W, B, W, site(s, 3), st));
   LinBwd l[3];
   for (int m = 0; m < 3; ++m)
     l[m] = LinBwd{wf + pl.V + m * BW, W, d2 + m * BW, W, B, W, W, P_[8 + 4 * m], G_[8 + 4 * m], G_[9 + 4 * m], d1 + m * BW, W};
-  OCEAN_TRY(linear_bwd_batch(l, 3, 0, st));
-  OCEAN_TRY(dropout_inplace(d1, W, 3 * B, W, W / s->heads, site(s, 0), st));
+  OCEAN_TRY(linear_bwd_batch(l, 3, 0, st, &d0, W / s->heads));
   for (int m = 0; m < 3; ++m)
     l[m] = LinBwd{wf + pl.P + m * BW, W, d1 + m * BW, W, B, W, W, P_[6 + 4 * m], G_[6 + 4 * m], G_[7 + 4 * m], d2 + m * BW, W};
   OCEAN_TRY(linear_bwd_batch(l, 3, 0, st));

@@ -2,21 +2,28 @@
 #pragma once
 #include "common.h"
 
+// Optional epilogue of a linear-layer GEMM: dropout on the output (numbered like dropout_inplace on the [rows, N]
+// matrix the output is rows [row0, row0 + M) of) and / or ReLU backward through a saved forward output.
+struct Epi { const DropoutP* drop = nullptr; int group = 1; int row0 = 0; const float* relu_mask = nullptr; int ld_mask = 0; };
 // y[M,N] = x[M,K] . W[N,K]^T (+ b) (ReLU)                (nn.Linear forward)
 int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy,
-               int M, int N, int K, int relu, hipStream_t s);
+               int M, int N, int K, int relu, hipStream_t s, const Epi* e = nullptr);
 // dx[M,K] (+= if accumulate) = dy[M,N] . W[N,K]          (nn.Linear data gradient)
 int linear_bwd_data(const float* dy, int lddy, const float* W, float* dx, int lddx,
-                    int M, int N, int K, int accumulate, hipStream_t s);
+                    int M, int N, int K, int accumulate, hipStream_t s, const Epi* e = nullptr);
 // dW[N,K] += dy[M,N]^T . x[M,K]                          (nn.Linear weight gradient, atomic accumulate)
 int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float* dW,
                       int M, int N, int K, hipStream_t s, float* db = nullptr);
 // Batched forms: up to kGemmBatchMax independent layers (the three modality branches) per launch.
 struct LinFwd { const float* x; int ldx; const float* W; const float* b; float* y; int ldy; int M, N, K; };
-int linear_fwd_batch(const LinFwd* l, int n, int relu, hipStream_t s);
+// drop: one dropout site over the entries' outputs stacked row-wise (entry q covers rows [q*M, (q+1)*M))
+int linear_fwd_batch(const LinFwd* l, int n, int relu, hipStream_t s, const DropoutP* drop = nullptr, int drop_group = 1);
 // one layer's backward: dW += dy^T x, db += colsum(dy), dx (+)= dy W; null outputs are skipped
 struct LinBwd { const float* x; int ldx; const float* dy; int lddy; int M, N, K; const float* W; float* dW; float* db; float* dx; int lddx; };
-int linear_bwd_batch(const LinBwd* l, int n, int accumulate_dx, hipStream_t s);
+// dx_drop / relu_masks: applied to the dx outputs (dropout site stacked as in linear_fwd_batch; relu_masks[q] is entry q's
+// saved forward output, leading dimension ld_mask)
+int linear_bwd_batch(const LinBwd* l, int n, int accumulate_dx, hipStream_t s, const DropoutP* dx_drop = nullptr, int drop_group = 1,
+                     const float* const* relu_masks = nullptr, int ld_mask = 0);
 struct ColSum { const float* a; int lda; int M, N; float* out; };
 int colsum_add_batch(const ColSum* c, int n, hipStream_t s);
 // out[N] += column sums of a[M,N]                         (bias gradients)

@@ -3,20 +3,28 @@
 #include "ops.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+static void apply_epi(GemmP& p, const Epi* e) {
+  if (!e) return;
+  if (e->drop) { p.drop = *e->drop; p.drop_group = e->group; p.drop_row0 = e->row0; }
+  p.relu_mask = e->relu_mask; p.ld_mask = e->ld_mask;
+}
+
 int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy,
-               int M, int N, int K, int relu, hipStream_t s) {
+               int M, int N, int K, int relu, hipStream_t s, const Epi* e) {
   GemmP p = gemm_defaults();
   p.A = x; p.lda = ldx; p.B = W; p.ldb = K; p.C = y; p.ldc = ldy;
   p.M = M; p.N = N; p.K = K; p.bias = b; p.relu = relu;
+  apply_epi(p, e);
   return ocean_launch_gemm(p, s);
 }
 
 int linear_bwd_data(const float* dy, int lddy, const float* W, float* dx, int lddx,
-                    int M, int N, int K, int accumulate, hipStream_t s) {
+                    int M, int N, int K, int accumulate, hipStream_t s, const Epi* e) {
   GemmP p = gemm_defaults();
   p.A = dy; p.lda = lddy; p.B = W; p.ldb = K; p.b_kn = 1; p.C = dx; p.ldc = lddx;
   p.M = M; p.N = K; p.K = N;
   if (accumulate) { p.R = dx; p.ldr = lddx; }
+  apply_epi(p, e);
   return ocean_launch_gemm(p, s);
 }
 
@@ -29,18 +37,20 @@ int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float*
   return ocean_launch_gemm(p, s);
 }
 
-int linear_fwd_batch(const LinFwd* l, int n, int relu, hipStream_t s) {
+int linear_fwd_batch(const LinFwd* l, int n, int relu, hipStream_t s, const DropoutP* drop, int drop_group) {
   if (n < 1 || n > kGemmBatchMax) return OCEAN_ERR_BAD_SHAPE;
   GemmP g[kGemmBatchMax];
   for (int q = 0; q < n; ++q) {
     g[q] = gemm_defaults();
     g[q].A = l[q].x; g[q].lda = l[q].ldx; g[q].B = l[q].W; g[q].ldb = l[q].K; g[q].C = l[q].y; g[q].ldc = l[q].ldy;
     g[q].M = l[q].M; g[q].N = l[q].N; g[q].K = l[q].K; g[q].bias = l[q].b; g[q].relu = relu;
+    if (drop) { g[q].drop = *drop; g[q].drop_group = drop_group; g[q].drop_row0 = q * l[q].M; }
   }
   return ocean_launch_gemm_batch(g, n, s);
 }
 
-int linear_bwd_batch(const LinBwd* l, int n, int accumulate_dx, hipStream_t s) {
+int linear_bwd_batch(const LinBwd* l, int n, int accumulate_dx, hipStream_t s, const DropoutP* dx_drop, int drop_group,
+                     const float* const* relu_masks, int ld_mask) {
   if (n < 1 || n > kGemmBatchMax) return OCEAN_ERR_BAD_SHAPE;
   GemmP g[kGemmBatchMax];
   int k = 0;
@@ -68,6 +78,8 @@ int linear_bwd_batch(const LinBwd* l, int n, int accumulate_dx, hipStream_t s) {
     g[k].A = l[q].dy; g[k].lda = l[q].lddy; g[k].B = l[q].W; g[k].ldb = l[q].K; g[k].b_kn = 1; g[k].C = l[q].dx; g[k].ldc = l[q].lddx;
     g[k].M = l[q].M; g[k].N = l[q].K; g[k].K = l[q].N;
     if (accumulate_dx) { g[k].R = l[q].dx; g[k].ldr = l[q].lddx; }
+    if (dx_drop) { g[k].drop = *dx_drop; g[k].drop_group = drop_group; g[k].drop_row0 = q * l[q].M; }
+    if (relu_masks) { g[k].relu_mask = relu_masks[q]; g[k].ld_mask = ld_mask; }
     ++k;
   }
   if (k > 0) OCEAN_TRY(ocean_launch_gemm_batch(g, k, s));
