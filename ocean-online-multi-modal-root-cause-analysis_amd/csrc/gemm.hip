@@ -590,9 +590,10 @@ inline int env_int(const char* name, int dflt) {
 }
 // development knobs (read once): OCEAN_GEMM_SMALL_BK (k-depth of the 64x64 tiles), OCEAN_GEMM_WG_CHUNK (minimum
 // reduction rows per block of a split row reduction), OCEAN_GEMM_WG_BIGK (row reductions at least this long use
-// 128x128 tiles)
+// 128x128 tiles), OCEAN_GEMM_WG_ATOMDIV (split limit sqrt(K / this); 0 = no limit)
 inline int small_bk() { static const int v = env_int("OCEAN_GEMM_SMALL_BK", 16) == 32 ? 32 : 16; return v; }
 inline int wg_chunk() { static const int v = env_int("OCEAN_GEMM_WG_CHUNK", 128); return v < 16 ? 16 : v; }
+inline int wg_atom_div() { static const int v = env_int("OCEAN_GEMM_WG_ATOMDIV", 2); return v; }
 inline long wg_big_k() { static const int v = env_int("OCEAN_GEMM_WG_BIGK", 8192); return v; }
 
 template <bool AKM, bool BKN>
@@ -621,6 +622,12 @@ int launch_mode(GemmBatch b, bool aligned, hipStream_t stream) {
       long want = (768 + blocks - 1) / blocks;
       const long max_split = (K + wg_chunk() - 1) / wg_chunk();    // >= wg_chunk reduction rows per block
       if (want > max_split) want = max_split;
+      // every block of a split adds its tile into the same addresses, and same-address atomics serialise: with s
+      // blocks the loop costs ~K/s and the adds ~s, so outputs of one or two tiles stop splitting near sqrt(K)
+      if (wg_atom_div() > 0) {
+        const long cap = (long)sqrt((double)K / wg_atom_div());
+        if (want > cap) want = cap;
+      }
       if (want < 1) want = 1;
       split = (int)want;
     }
