@@ -89,16 +89,32 @@ inline int pi_bn(const DcnnPlan& p, int j, int k) { return p.is_block[j] ? pi_bl
 // ------------------------------------------------------------------ kernels
 // stats: [2][C] sums, or - with nslots > 0 - nslots copies of them that are added up here (the convolution epilogue's
 // slot copies, when no other rank's sums have to be added in between)
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, int nslots, double n, const float* __restrict__ gamma,
+constexpr int kFinCh = 32, kFinParts = 8;
+__global__ __launch_bounds__(kFinCh * kFinParts) void bn_finalize_kernel(const double* __restrict__ stats, int nslots, double n, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv,
                                    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
                                    float* __restrict__ shift, int C, int training, float eps, float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  // 32 channels per block, 8 threads per channel: each takes every 8th slot copy (loads that do not depend on each
+  // other), then the 8 partial sums meet in shared memory; one thread per channel walking all copies in turn spent
+  // ~10 us on a chain of dependent L2 round trips
+  __shared__ double part[2][kFinParts][kFinCh];
+  const int cl = threadIdx.x % kFinCh, pt = threadIdx.x / kFinCh;
+  const int c = blockIdx.x * kFinCh + cl;
+  if (training) {
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C) {
+      if (nslots <= 0) { if (pt == 0) { a1 = stats[c]; a2 = stats[C + c]; } }
+      else for (int q = pt; q < nslots; q += kFinParts) { a1 += stats[(size_t)q * 2 * C + c]; a2 += stats[(size_t)q * 2 * C + C + c]; }
+    }
+    part[0][pt][cl] = a1; part[1][pt][cl] = a2;
+    __syncthreads();
+  }
+  if (pt != 0 || c >= C) return;
   float mu, var;
   if (training) {
-    double s1 = stats[c], s2 = stats[C + c];
-    for (int q = 1; q < nslots; ++q) { s1 += stats[(size_t)q * 2 * C + c]; s2 += stats[(size_t)q * 2 * C + C + c]; }
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < kFinParts; ++q) { s1 += part[0][q][cl]; s2 += part[1][q][cl]; }
     const double m = s1 / n;
     double v = s2 / n - m * m;
     if (v < 0.0) v = 0.0;
@@ -339,7 +355,7 @@ int bn_finalize(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, float* con
                 hipStream_t st) {
   const int C = pl.width[j];
   const double n = (double)(s->bn_count > 0 ? s->bn_count : pl.M);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, st,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, kFinCh)), dim3(kFinCh * kFinParts), 0, st,
                      reinterpret_cast<const double*>(ws + (from_slots ? pl.fslots[j] : pl.stats[j])), from_slots ? kStatSlots : 0, n, params[pi_bn(pl, j, 1)], params[pi_bn(pl, j, 2)],
                      params[pi_bn(pl, j, 3)], params[pi_bn(pl, j, 4)], ws + pl.mean[j], ws + pl.invstd[j],
                      ws + pl.scale[j], ws + pl.shift[j], C, s->training, s->eps, s->momentum);

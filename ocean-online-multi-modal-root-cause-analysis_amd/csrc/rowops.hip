@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdBatch batch, int
 
 // Each wave walks rows row0 + w, row0 + w + kWaves, ... of its block's chunk so the
 // per-column gamma/beta partial sums stay in registers (up to 16 columns per lane).
-constexpr int kLnRowsPerBlock = 32;
+constexpr int kLnRowsPerBlock = 8;    // two rows per wave: a wave works through its rows one dependent round trip after the other
 constexpr int kMaxColsPerLane = 16;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdBatch batch, int lddy, int ldx, int lddx, int rows, int W, DropoutP dp) {
   dp = dropout_resolve(dp);
