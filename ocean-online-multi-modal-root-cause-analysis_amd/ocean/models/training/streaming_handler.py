@@ -7,6 +7,12 @@ StreamingHandler): bounded per-stream deques that drop when full, one daemon
 worker that every `processing_interval` seconds drains up to `batch_size`
 samples per active stream and hands them to OnlineLearner.process_batch in
 chunks of `batch_size`, swallowing (and logging) per-batch exceptions.
+
+Addition (off by default): `event_driven=True` wakes the worker as soon as one
+stream holds `wake_samples` samples instead of at the next polling tick, so the
+delay between a window arriving and its update is the update time, not up to
+`processing_interval`.  A cycle does the same work either way; the interval
+stays the upper bound on the wait.
 """
 from __future__ import annotations
 
@@ -37,6 +43,7 @@ class DataStream:
         self.is_active = False
         self.total_samples = 0
         self.dropped_samples = 0
+        self._on_sample: Optional[Callable[["DataStream"], None]] = None    # set by an event-driven StreamProcessor
 
     def add_sample(self, sample: Any) -> bool:
         if len(self.buffer) >= self.buffer_size:
@@ -44,6 +51,9 @@ class DataStream:
             return False
         self.buffer.append(sample)
         self.total_samples += 1
+        notify = self._on_sample
+        if notify is not None:
+            notify(self)
         return True
 
     def get_samples(self, max_samples: Optional[int] = None) -> List[Any]:
@@ -129,9 +139,13 @@ class MemoryManager:
 
 class StreamProcessor:
     def __init__(self, online_learner: OnlineLearner, max_streams: int = 10, processing_interval: float = 1.0,
-                 batch_size: int = 32):
+                 batch_size: int = 32, event_driven: bool = False, wake_samples: Optional[int] = None):
         self.online_learner, self.max_streams = online_learner, max_streams
         self.processing_interval, self.batch_size = processing_interval, batch_size
+        self.event_driven = bool(event_driven)
+        self.wake_samples = max(1, int(wake_samples if wake_samples is not None else batch_size))
+        self._wake = threading.Event()
+        self.early_wakeups = 0
         self.streams: Dict[str, DataStream] = {}
         self.processing_queue: queue.PriorityQueue = queue.PriorityQueue()
         self.is_processing = False
@@ -151,13 +165,24 @@ class StreamProcessor:
             return False
         self.streams[stream.stream_id] = stream
         stream.is_active = True
+        if self.event_driven:
+            stream._on_sample = self._sample_arrived
         return True
+
+    def _sample_arrived(self, stream: DataStream) -> None:
+        # producer side (any thread): one length test, and a set() only when a full batch is waiting
+        if len(stream.buffer) >= self.wake_samples:
+            self._wake.set()
+
+    def _batch_waiting(self) -> bool:
+        return any(s.is_active and len(s.buffer) >= self.wake_samples for s in list(self.streams.values()))
 
     def remove_stream(self, stream_id: str) -> bool:
         stream = self.streams.pop(stream_id, None)
         if stream is None:
             return False
         stream.is_active = False
+        stream._on_sample = None
         return True
 
     def start_processing(self):
@@ -171,6 +196,7 @@ class StreamProcessor:
 
     def stop_processing(self):
         self.is_processing = False
+        self._wake.set()            # an event-driven worker may be waiting on it
         if self.processor_thread:
             self.processor_thread.join(timeout=10.0)
         self.memory_manager.stop_monitoring()
@@ -196,8 +222,17 @@ class StreamProcessor:
         while self.is_processing:
             try:
                 t0 = time.time()
+                self._wake.clear()
                 self.process_once()
                 remaining = self.processing_interval - (time.time() - t0)
+                if self.event_driven:
+                    # samples that arrived during the update may already make a batch: then no wait at all
+                    if self.is_processing and remaining > 0 and not self._batch_waiting():
+                        if self._wake.wait(timeout=remaining) and self.is_processing:
+                            self.early_wakeups += 1
+                    elif remaining > 0:
+                        self.early_wakeups += 1
+                    continue
                 while self.is_processing and remaining > 0:
                     time.sleep(min(0.05, remaining))
                     remaining = self.processing_interval - (time.time() - t0)
@@ -226,6 +261,8 @@ class StreamProcessor:
                                  "active_streams": sum(1 for s in self.streams.values() if s.is_active),
                                  "total_streams": len(self.streams), "is_processing": self.is_processing,
                                  "memory_stats": self.memory_manager.get_memory_stats()}
+        if self.event_driven:
+            stats.update({"event_driven": True, "wake_samples": self.wake_samples, "early_wakeups": self.early_wakeups})
         if self.processing_times:
             t = list(self.processing_times)
             stats.update({"avg_processing_time": np.mean(t), "max_processing_time": np.max(t), "processing_time_std": np.std(t)})
@@ -249,12 +286,13 @@ class StreamProcessor:
 
 class StreamingHandler:
     def __init__(self, online_learner: OnlineLearner, max_concurrent_streams: int = 10, processing_interval: float = 1.0,
-                 enable_memory_management: bool = True):
+                 enable_memory_management: bool = True, event_driven: bool = False, wake_samples: Optional[int] = None):
         self.online_learner = online_learner
         self.max_concurrent_streams, self.processing_interval = max_concurrent_streams, processing_interval
         self.enable_memory_management = enable_memory_management
         self.stream_processor = StreamProcessor(online_learner=online_learner, max_streams=max_concurrent_streams,
-                                                processing_interval=processing_interval)
+                                                processing_interval=processing_interval, event_driven=event_driven,
+                                                wake_samples=wake_samples)
         self.stream_callbacks: Dict[str, Callable] = {}
         self.is_active = False
         self.start_time: Optional[datetime] = None

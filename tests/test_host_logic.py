@@ -181,6 +181,58 @@ def test_streaming_handler_batches_drops_and_survives_errors(tmp_path):
     assert h.remove_stream("a") and not h.remove_stream("a")
 
 
+class _TimedLearner(_StubLearner):
+    def __init__(self):
+        super().__init__()
+        self.done_at = []
+
+    def process_batch(self, batch):
+        out = super().process_batch(batch)
+        now = time.time()
+        self.done_at.extend(now - t_in for _, t_in in batch)
+        return out
+
+
+def test_event_driven_processor_updates_when_a_window_is_full_not_at_the_next_tick():
+    """Scheduling only (reference polling loop: ocean/models/training/streaming_handler.py:303-358): with a 2 s
+    interval the polled worker makes a full window wait for the tick; the event-driven one starts its cycle when the
+    window's last sample arrives.  Cycle contents are the same: up to batch_size samples per active stream."""
+    from ocean.models.training import StreamingHandler
+    learner = _TimedLearner()
+    h = StreamingHandler(learner, max_concurrent_streams=4, processing_interval=2.0, event_driven=True, wake_samples=8)
+    assert h.create_stream("a") and h.create_stream("b")
+    h.start()
+    time.sleep(0.2)                                   # worker is now waiting for its tick
+    for w in range(3):                                # three windows of 8 on stream a, a few strays on b
+        h.add_sample_to_stream("b", ("b", time.time()))
+        for i in range(8):
+            h.add_sample_to_stream("a", ("a", time.time()))
+        t0 = time.time()
+        while h.stream_processor.processed_samples < 9 * (w + 1) and time.time() - t0 < 1.0:
+            time.sleep(0.005)
+    h.stop()
+    assert h.stream_processor.processed_samples == 27
+    assert max(learner.done_at) < 0.5                 # every sample was in an update long before the 2 s tick
+    assert [len(b) for b in learner.batches] == [9, 9, 9]      # same cycle contents as a polling cycle would have
+    stats = h.stream_processor.get_processing_stats()
+    assert stats["event_driven"] and stats["early_wakeups"] >= 3 and stats["wake_samples"] == 8
+    # a partial window still goes out at the tick, as in the polled mode
+    h2 = StreamingHandler(_TimedLearner(), processing_interval=0.1, event_driven=True, wake_samples=8)
+    h2.create_stream("a")
+    h2.start()
+    for i in range(3):
+        h2.add_sample_to_stream("a", ("a", time.time()))
+    t0 = time.time()
+    while h2.stream_processor.processed_samples < 3 and time.time() - t0 < 2.0:
+        time.sleep(0.01)
+    h2.stop()
+    assert h2.stream_processor.processed_samples == 3
+    # the default stays the reference's polling loop, with no hook on the streams
+    h3 = StreamingHandler(_StubLearner())
+    h3.create_stream("a")
+    assert h3.stream_processor.streams["a"]._on_sample is None and "event_driven" not in h3.stream_processor.get_processing_stats()
+
+
 def test_config_round_trip_and_defaults():
     import ocean
     cfg = ocean.default_config()
