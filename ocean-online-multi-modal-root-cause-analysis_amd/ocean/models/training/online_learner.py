@@ -24,7 +24,7 @@ from ... import _hip
 from ...configs import OCEANConfig
 from ...data.data_types import DatasetSample
 from ...optim import FusedAdam
-from ...staging import BatchStager
+from ...staging import BatchStager, ReplayPool
 from ..ocean_model import OCEANModel
 
 logger = logging.getLogger(__name__)
@@ -40,6 +40,7 @@ class MemoryBuffer:
         self.buffer: deque = deque(maxlen=max_size)
         self.importance_scores: deque = deque(maxlen=max_size)
         self.timestamps: deque = deque(maxlen=max_size)
+        self.on_evict = None        # optional callable(sample): told which sample an eviction removed
 
     def add(self, sample: DatasetSample, importance_score: float = 1.0):
         if len(self.buffer) >= self.max_size:
@@ -49,6 +50,8 @@ class MemoryBuffer:
         self.timestamps.append(datetime.now())
 
     def _drop_at(self, idx: int):
+        if self.on_evict is not None:
+            self.on_evict(self.buffer[idx])
         for name in ("buffer", "importance_scores", "timestamps"):
             items = list(getattr(self, name))
             items.pop(idx)
@@ -57,6 +60,8 @@ class MemoryBuffer:
     def _remove_sample(self):
         if self.retention_strategy == "fifo":
             # the sample deque evicts its own oldest entry on append
+            if self.on_evict is not None and len(self.buffer) > 0:
+                self.on_evict(self.buffer[0])
             self.importance_scores.popleft()
             self.timestamps.popleft()
         elif self.retention_strategy == "random" and len(self.buffer) > 0:
@@ -206,6 +211,10 @@ class OnlineLearner:
         self.pinned_staging = True
         self._stager: Optional[BatchStager] = None
         self._prefetch_next: Optional[List[DatasetSample]] = None
+        # device_replay: samples taken into the memory buffer are also kept in HBM (ocean/staging.py ReplayPool), so
+        # experience_replay gathers its batch on the device instead of re-collating it from host tensors
+        self.device_replay = True
+        self._replay_pool: Optional[ReplayPool] = None
         self._mods = None
         self._prefetched = None
         self._graph_seen: Dict[Any, int] = defaultdict(int)
@@ -255,7 +264,7 @@ class OnlineLearner:
             self._apply_update(losses["total_loss"])
         host = self._losses_to_host(losses)
         importance_score = host["total_loss"]
-        self.memory_buffer.add(sample, importance_score)
+        self._remember(sample, importance_score)
         if update_model:
             current_lr = self.lr_scheduler.step(host["total_loss"], self.optimizer)
             self.performance_history["loss"].append(host["total_loss"])
@@ -351,10 +360,30 @@ class OnlineLearner:
             self._graphed[key] = step
         return step.replay(self, metrics, logs, labels)
 
+    def _remember(self, sample: DatasetSample, importance_score: float) -> None:
+        """memory_buffer.add (online_learner.py:338), plus the sample's device copy when device_replay is on."""
+        pool = self._replay_pool
+        if self.device_replay and pool is None and self.model.device.type == "cuda":
+            pool = self._replay_pool = ReplayPool(self.model.device, self.memory_buffer.max_size)
+            self.memory_buffer.on_evict = pool.evict
+        elif pool is not None and self.memory_buffer.on_evict != pool.evict:      # the buffer object was replaced
+            pool.clear()
+            self.memory_buffer.on_evict = pool.evict
+        self.memory_buffer.add(sample, importance_score)         # evicts first when full, which frees a pool row
+        if pool is not None and self.device_replay:
+            pool.put(sample)
+
     def experience_replay(self, replay_batch_size: int = 32) -> Optional[Dict[str, float]]:
+        """One update on a batch drawn from the memory buffer (online_learner.py:433-453).  The draw is the
+        buffer's; with device_replay the batch is gathered from the samples' device copies."""
         if len(self.memory_buffer) < replay_batch_size:
             return None
-        results = self.process_batch(self.memory_buffer.sample(replay_batch_size))
+        batch = self.memory_buffer.sample(replay_batch_size)
+        staged = self._replay_pool.gather(batch) if (self.device_replay and self._replay_pool is not None) else None
+        if staged is not None:
+            results = self.process_tensors(staged[0], batch[0].graph, staged[1], staged[2])
+        else:
+            results = self.process_batch(batch)
         results["replay"] = True
         return results
 
@@ -428,6 +457,7 @@ class OnlineLearner:
 
     def reset(self):
         self.memory_buffer = MemoryBuffer(max_size=self.config.training.sliding_window_size, retention_strategy="importance")
+        self._replay_pool = None
         self.sliding_window.reset()
         self.lr_scheduler.reset()
         self.performance_history.clear()

@@ -116,3 +116,82 @@ class BatchStager:
         slot = self._find(tensors)
         if slot is not None and slot.done is not None:
             slot.done.record(torch.cuda.current_stream(self.device))
+
+
+class ReplayPool:
+    """Device-resident copy of the samples a MemoryBuffer holds, for experience replay.
+
+    The reference rebuilds every replay batch from the Python deque: three torch.stack calls over per-sample host
+    tensors and a host-to-device transfer (ocean/models/training/online_learner.py:433-453 via :378-393), although
+    each of those samples already crossed PCIe once when it was first processed.  Here a sample's three tensors are
+    written into one row of three preallocated device tensors when the buffer takes it in, the row is handed back
+    when the buffer evicts it, and a replay batch is three row gathers on the device.  Which samples make a batch
+    is still decided by MemoryBuffer.sample (same random draws); the pool only changes where their bytes come from.
+
+    The first sample fixes the row shapes; a sample of another shape or dtype, or one that arrives when no row is
+    free, is simply not pooled, and gather() answers None for a batch that contains such a sample (the caller then
+    collates that batch from the host copies).
+    """
+
+    def __init__(self, device, capacity: int):
+        self.device, self.capacity = torch.device(device), int(capacity)
+        self._rows: Optional[List[torch.Tensor]] = None          # [capacity, ...] per field
+        self._shapes: Optional[Tuple] = None
+        self._slot_of: Dict[int, int] = {}                       # id(sample) -> row
+        self._owner: List[object] = [None] * self.capacity       # row -> the sample itself: keeps its id from being reused
+        self._free: List[int] = list(range(self.capacity - 1, -1, -1))
+
+    def __len__(self) -> int:
+        return len(self._slot_of)
+
+    def __contains__(self, sample) -> bool:
+        return id(sample) in self._slot_of
+
+    @staticmethod
+    def _fields(sample):
+        return sample.metrics, sample.logs, sample.label
+
+    def put(self, sample) -> bool:
+        """Copy the sample's tensors into a free row (asynchronously on the current stream when they sit in pinned
+        memory, as an ordinary copy otherwise).  False when the sample cannot be pooled."""
+        fields = self._fields(sample)
+        if any((not torch.is_tensor(f)) or f.dtype != torch.float32 for f in fields):
+            return False
+        shapes = tuple(tuple(f.shape) for f in fields)
+        if self._rows is None:
+            self._shapes = shapes
+            self._rows = [torch.empty((self.capacity, *s), dtype=torch.float32, device=self.device) for s in shapes]
+        if shapes != self._shapes or id(sample) in self._slot_of or not self._free:
+            return id(sample) in self._slot_of
+        row = self._free.pop()
+        for dst, src in zip(self._rows, fields):
+            dst[row].copy_(src, non_blocking=True)
+        self._slot_of[id(sample)] = row
+        self._owner[row] = sample
+        return True
+
+    def evict(self, sample) -> None:
+        row = self._slot_of.pop(id(sample), None)
+        if row is not None:
+            self._owner[row] = None
+            self._free.append(row)
+
+    def clear(self) -> None:
+        self._slot_of.clear()
+        self._owner = [None] * self.capacity
+        self._free = list(range(self.capacity - 1, -1, -1))
+
+    def gather(self, samples) -> Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """(metrics [B,...], logs [B,...], labels [B,...]) on the device, rows in the order of `samples`; None when
+        one of them is not in the pool."""
+        try:
+            rows = [self._slot_of[id(s)] for s in samples]
+        except KeyError:
+            return None
+        if not rows:
+            return None
+        idx = torch.tensor(rows, dtype=torch.long)
+        if self.device.type == "cuda":
+            idx = idx.pin_memory().to(self.device, non_blocking=True)
+        m, l, y = (r.index_select(0, idx) for r in self._rows)
+        return m, l, y

@@ -111,3 +111,97 @@ def test_process_batch_staged_equals_stacked():
     for (n, p), q in zip(ma.named_parameters(), mb.parameters()):
         scale = max(q.double().abs().max().item(), 1e-3)
         assert (p.double() - q.double()).abs().max().item() <= 2e-3 * scale, n
+
+
+def test_replay_pool_follows_the_memory_buffer_through_evictions():
+    """Rows are taken on add, handed back on eviction (all three retention strategies), and a gathered batch holds
+    the samples' own bytes in the order MemoryBuffer.sample chose."""
+    import numpy as np
+    from ocean.models.training.online_learner import MemoryBuffer
+    from ocean.staging import ReplayPool
+    for strategy in ("importance", "fifo", "random"):
+        buf = MemoryBuffer(max_size=5, retention_strategy=strategy)
+        pool = ReplayPool("cpu", 5)
+        buf.on_evict = pool.evict
+        np.random.seed(3)
+        samples = _samples(12, 40)
+        for k, s in enumerate(samples):
+            buf.add(s, importance_score=float((7 * k) % 11) + 0.5)
+            assert pool.put(s)
+            assert len(pool) == len(buf) == min(k + 1, 5)
+            assert all(b in pool for b in buf.buffer)
+        assert sorted(pool._free + list(pool._slot_of.values())) == list(range(5))
+        batch = buf.sample(3)
+        m, l, y = pool.gather(batch)
+        assert torch.equal(m, torch.stack([s.metrics for s in batch]))
+        assert torch.equal(l, torch.stack([s.logs for s in batch]))
+        assert torch.equal(y, torch.stack([s.label for s in batch]))
+        held = {id(b) for b in buf.buffer}
+        evicted = [s for s in samples if id(s) not in held]
+        assert pool.gather([batch[0], evicted[0]]) is None         # a batch with an unpooled sample is not served
+    # samples that do not fit the pool's row shape, or arrive when it is full, are left to the host path
+    pool = ReplayPool("cpu", 2)
+    a, b, c = _samples(3, 41)
+    odd = _samples(1, 42, T=9)[0]
+    assert pool.put(a) and not pool.put(odd) and pool.put(b) and not pool.put(c)
+    assert pool.put(a) and len(pool) == 2                          # already pooled: still one row
+    pool.evict(a)
+    assert pool.put(c) and pool.gather([c, b]) is not None and pool.gather([a]) is None
+    pool.clear()
+    assert len(pool) == 0 and len(pool._free) == 2
+
+
+@pytest.mark.gpu
+def test_experience_replay_from_the_device_pool_equals_replay_from_host_samples():
+    """Two learners see the same stream of process_sample calls and then replay with the same random draws; one
+    gathers its replay batches from HBM, the other collates them from the host samples as the reference does
+    (ocean/models/training/online_learner.py:433-453).  Same batches, same updates."""
+    import numpy as np
+    import ocean
+    from ocean.data import ServiceGraph
+    from ocean.models.training import OnlineLearner
+    from oracle import synth
+
+    def learner(device_replay):
+        cfg = ocean.OCEANConfig()
+        cfg.model.dcnn_channels, cfg.model.dcnn_dilation_rates = [8, 16], [1, 2]
+        cfg.model.hidden_dim = cfg.model.attention_dim = 16
+        cfg.model.attention_num_heads, cfg.model.gnn_num_heads = 4, 2
+        cfg.model.fusion_projection_dim, cfg.model.num_services = 32, 6
+        cfg.data.metrics_features, cfg.data.log_embedding_dim, cfg.data.graph_features = 5, 24, 7
+        cfg.training.sliding_window_size = 6                      # memory buffer capacity: forces evictions below
+        m = ocean.OCEANModel(cfg)
+        m.load_state_dict(synth.fill_state_dict(m.state_dict(), 3))
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        m = m.cuda()
+        m.contrastive_negatives = "in_batch"
+        lrn = OnlineLearner(m, cfg)
+        lrn.device_replay = device_replay
+        return m, lrn
+
+    graph = ServiceGraph(adjacency_matrix=synth.random_digraph(6, 2.0, 4),
+                         node_features=torch.randn(6, 7, generator=torch.Generator().manual_seed(1)))
+    (ma, la), (mb, lb) = learner(True), learner(False)
+    stream = _samples(9, 77, graph=graph)
+    for s in stream:                                              # update_model=False: identical scores on both sides
+        ra, rb = la.process_sample(s, update_model=False), lb.process_sample(s, update_model=False)
+        assert abs(ra["importance_score"] - rb["importance_score"]) <= 1e-6 * max(1.0, abs(rb["importance_score"]))
+    assert len(la.memory_buffer) == 6 and len(la._replay_pool) == 6 and lb._replay_pool is None
+    assert [id(s) for s in la.memory_buffer.buffer] == [id(s) for s in lb.memory_buffer.buffer]
+    for k in range(4):
+        np.random.seed(10 + k)
+        ra = la.experience_replay(4)
+        np.random.seed(10 + k)
+        rb = lb.experience_replay(4)
+        assert ra["replay"] and rb["replay"] and ra["batch_size"] == rb["batch_size"] == 4
+        assert abs(ra["batch_loss"] - rb["batch_loss"]) <= 1e-5 * max(1.0, abs(rb["batch_loss"]))
+    assert la.experience_replay(7) is None                        # fewer samples than asked for: the reference's None
+    for (n, p), q in zip(ma.named_parameters(), mb.parameters()):
+        scale = max(q.double().abs().max().item(), 1e-3)
+        assert (p.double() - q.double()).abs().max().item() <= 2e-3 * scale, n
+    la.reset()
+    assert la._replay_pool is None and len(la.memory_buffer) == 0

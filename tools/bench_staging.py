@@ -68,3 +68,45 @@ def case(name, N, deg, B, T, steps):
 
 case("C3 (256 services, batch 1024, seq_len 128)", 256, 8.0, 1024, 128, 20)
 case("C5 window (64 services, batch 8, seq_len 64)", 64, 4.0, 8, 64, 200)
+
+
+def replay_case(name, N, deg, T, held, batch, steps):
+    """experience_replay(batch) from a memory buffer of `held` samples: gathered from the device pool vs collated from
+    the host samples (pinned ring on), same draws."""
+    import numpy as np
+    cfg = ocean.default_config()
+    cfg.model.num_services = N
+    nf = torch.randn(N, 12, generator=g(7))
+    adj = (torch.rand(N, N, generator=g(11)) < deg / N).float()
+    adj.fill_diagonal_(0.0)
+    graph = ServiceGraph(adjacency_matrix=adj, node_features=nf)
+    metrics, logs = torch.randn(held, T, 12, generator=g(1000)), torch.randn(held, 768, generator=g(2000))
+    labels = torch.zeros(held, N)
+    labels[torch.arange(held), torch.randint(0, N, (held,), generator=g(3000))] = 1.0
+    samples = [DatasetSample(metrics=metrics[i].clone(), logs=logs[i].clone(), graph=graph, label=labels[i].clone(),
+                             timestamp=datetime.now()) for i in range(held)]
+    for mode in ("replay batch gathered from the device pool", "replay batch collated from host samples (pinned ring)"):
+        torch.manual_seed(42)
+        m = ocean.OCEANModel(cfg).to(dev)
+        m.contrastive_negatives = "in_batch"
+        learner = OnlineLearner(m, cfg)
+        learner.use_hip_graph = True
+        learner.device_replay = "device pool" in mode
+        for k, s in enumerate(samples):
+            learner._remember(s, 1.0 + (k % 7))
+        np.random.seed(5)
+        for _ in range(4):
+            learner.experience_replay(batch)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            learner.experience_replay(batch)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        print(json.dumps({"config": name, "input": mode, "ms_p50": ts[len(ts) // 2] * 1e3, "ms_mean": sum(ts) / len(ts) * 1e3,
+                          "samples_per_s": batch / (sum(ts) / len(ts)), "batch": batch, "buffer": held}), flush=True)
+
+
+replay_case("experience replay, C5 shape (64 services, seq_len 64), 32 of 512 buffered samples", 64, 4.0, 64, 512, 32, 200)
