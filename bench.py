@@ -114,6 +114,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
+    # OCEAN_BENCH_REHEARSE=1: every rank uses GPU 0 and the collectives go through gloo, so that the N > 1 control flow
+    # (phased BatchNorm statistics, gathers, gradient bucket, barriers, max over ranks) can be run on a one-GPU box.
+    # Its numbers mean nothing: the ranks share one GPU.
+    rehearse = os.environ.get("OCEAN_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("OCEAN_BENCH_REHEARSE_TIMEOUT", "90")), exit=True)   # a stuck collective names itself
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # OCEAN_BENCH_DIST=1 takes the data-parallel code path (RCCL process group, collectives, eager launches) with a
@@ -123,7 +131,29 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # gloo's device-tensor collectives do not complete with two processes on one GPU: stage through the host
+            _bc, _ar, _ag = dist.broadcast, dist.all_reduce, dist.all_gather_into_tensor
+
+            def _broadcast(t, src=0, group=None):
+                c = t.detach().cpu()
+                _bc(c, src=src, group=group)
+                t.detach().copy_(c)
+
+            def _all_reduce(t, op=dist.ReduceOp.SUM, group=None):
+                c = t.detach().cpu()
+                _ar(c, op=op, group=group)
+                t.detach().copy_(c)
+
+            def _all_gather_into_tensor(out, x, group=None):
+                c = torch.empty(out.shape, dtype=out.dtype)
+                _ag(c, x.detach().cpu(), group=group)
+                out.copy_(c)
+
+            dist.broadcast, dist.all_reduce, dist.all_gather_into_tensor = _broadcast, _all_reduce, _all_gather_into_tensor
+        else:
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     import ocean
     from ocean import _hip
@@ -185,7 +215,7 @@ def main():
             "config": {"workload": f"BASELINE configs[2] (C3): {N} services (ER graph, in-degree 8), batch {B} per GPU, seq_len {T}, "
                                    "online update step = fwd + BCE/InfoNCE(in-batch) loss + bwd + clip(1.0) + Adam, "
                                    "reference default hyper-parameters (dropout 0.1: every graph replica computed)",
-                       "global_batch": world * B, "seq_len": T, "services": N, "parallelism": f"dp{world}",
+                       "global_batch": world * B, "seq_len": T, "services": N, "parallelism": f"dp{world}" + (" (rehearsal: all ranks on one GPU, gloo)" if rehearse else ""),
                        "launch": "hip-graph replay" if learner._graphed else "eager"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": recorded_traffic(dom["kernel"]),

@@ -17,7 +17,7 @@ import torch
 
 from . import _hip
 
-_CHUNK = 16384
+_CHUNK = 2048     # elements per block of the update kernels: ~1700 blocks for 3.3 M parameters (330 blocks of 16384 left most CUs idle)
 
 
 class FusedAdam(torch.optim.Optimizer):
