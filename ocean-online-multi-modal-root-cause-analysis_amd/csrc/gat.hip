@@ -33,6 +33,15 @@ struct GatK {
                                       // input is the same for all replicas; only the dropout masks differ)
 };
 
+// The layer's output stage y = dropout(relu(headmix(agg) + bias)) (+ xin), for the kernels that apply it to the
+// aggregated row while it is still in registers (y == nullptr: left to gat_epilogue_kernel).
+struct GatEpi {
+  const float* bias; const float* xin; float* y;
+  int xin_rows;                       // > 0: xin holds one replica of that many rows, read by all
+  int concat;
+  DropoutP fd;
+};
+
 constexpr int kWavesPerBlock = 4;
 
 template <int CPL>
@@ -443,10 +452,12 @@ template <int CPL, int HLOG>
 __global__ __launch_bounds__(kTileWaves * 64) void gat_aggregate_tile_kernel(GatK g, int npb, int chunks, const float* __restrict__ Z,
                                                                              const float* __restrict__ a_s,
                                                                              const float* __restrict__ a_d, float* __restrict__ agg,
-                                                                             float* __restrict__ smax, float* __restrict__ sden) {
+                                                                             float* __restrict__ smax, float* __restrict__ sden,
+                                                                             GatEpi epi) {
   constexpr int H = 1 << HLOG, EPW = 64 >> HLOG;
   constexpr int RB = CPL <= 2 ? 8 : 4, GB = EPW < RB ? EPW : RB;   // rows in flight per wave
   g.att_drop = dropout_resolve(g.att_drop);
+  epi.fd = dropout_resolve(epi.fd);
   extern __shared__ float lds[];
   const int N = g.N, E = g.E;
   float* as_l = lds;                                         // [N*H]   source logits of this replica
@@ -473,6 +484,12 @@ __global__ __launch_bounds__(kTileWaves * 64) void gat_aggregate_tile_kernel(Gat
   // lane k holds the edge range of the k-th node this wave will visit (npb <= 64 * kTileWaves)
   const int imine = min(i0 + wave + lane * kTileWaves, N - 1);
   const int rp0v = g.rp_in[imine], rp1v = g.rp_in[imine + 1];
+  // output stage: a lane's channels c0 .. c0+CPL-1 belong to head hk; with head mixing = mean the lanes of head 0 end
+  // up with the sums and write channel (c0 + k) of the C-wide output
+  const int Cw = g.HC >> HLOG;
+  float bias_r[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) bias_r[k] = epi.y != nullptr ? epi.bias[epi.concat ? c0 + k : (c0 + k) % Cw] : 0.f;
   // wait for them here: left to the compiler, the wait lands at the top of the node loop, where it also waits for the
   // previous node's output stores to be acknowledged
   __builtin_amdgcn_s_waitcnt(kWaitVm0);
@@ -571,7 +588,32 @@ __global__ __launch_bounds__(kTileWaves * 64) void gat_aggregate_tile_kernel(Gat
     const float inv = __builtin_amdgcn_rcpf(dl[hk] + 1e-16f);
 #pragma unroll
     for (int k = 0; k < CPL; ++k) acc[k] *= inv;
-    store_row<CPL>(agg + node * g.HC + c0, acc);
+    store_row<CPL>(agg + node * g.HC + c0, acc);     // kept: the backward pass takes the ReLU mask from it
+    if (epi.y != nullptr) {
+      const int od = epi.concat ? g.HC : Cw;
+      float o[CPL];
+#pragma unroll
+      for (int k = 0; k < CPL; ++k) {
+        float v = acc[k];
+        if (!epi.concat) {
+#pragma unroll
+          for (int sh = 64 >> HLOG; sh < 64; sh <<= 1) v += __shfl_xor(v, sh);     // sum over the heads
+          v *= 1.0f / (float)H;
+        }
+        v = fmaxf(v + bias_r[k], 0.f);
+        const long idx = node * od + c0 + k;
+        if (epi.fd.p > 0.f) v *= dropout_keep(epi.fd, (uint64_t)idx);
+        o[k] = v;
+      }
+      if (epi.concat || hk == 0) {
+        if (epi.xin != nullptr) {
+          const float* xr = epi.xin + (epi.xin_rows > 0 ? (long)i : node) * od + c0;
+#pragma unroll
+          for (int k = 0; k < CPL; ++k) o[k] += xr[k];
+        }
+        store_row<CPL>(epi.y + node * od + c0, o);
+      }
+    }
   }
 }
 
@@ -1258,8 +1300,12 @@ int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features, const in
     else
       GAT_DISPATCH(gat_scores_kernel, g, ws + pl.Z[l], params[pg_layer(l, 1)], params[pg_layer(l, 2)], ws + pl.as_[l], ws + pl.ad[l]);
     if (tile_edges(pl, s->E)) {
+      // the output stage rides along: the aggregated row is still in registers when it is stored
+      const bool fused = getenv("OCEAN_GAT_NO_FUSED_EPI") == nullptr;       // measurement switch, read per call
+      const GatEpi epi{params[pg_layer(l, 3)], pl.residual[l] ? xin : nullptr, fused ? ws + pl.y[l] : nullptr, shared ? s->N : 0, pl.concat[l], feat_drop(s, l)};
       GAT_DISPATCH_TILE(gat_aggregate_tile_kernel, tile_lds_fwd(pl, s->E), ws + pl.Z[l], ws + pl.as_[l], ws + pl.ad[l], ws + pl.agg[l],
-                        ws + pl.smax[l], ws + pl.sden[l]);
+                        ws + pl.smax[l], ws + pl.sden[l], epi);
+      if (fused) { xin = ws + pl.y[l]; continue; }
     } else if (fast_edges(pl)) {
       GAT_DISPATCH_FAST(gat_aggregate_fast_kernel, ws + pl.Z[l], ws + pl.as_[l], ws + pl.ad[l], ws + pl.agg[l], ws + pl.smax[l], ws + pl.sden[l]);
     } else {

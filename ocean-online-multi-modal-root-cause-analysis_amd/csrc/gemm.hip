@@ -588,10 +588,9 @@ inline int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-// development knobs (read once): OCEAN_GEMM_SMALL_BK (k-depth of the 64x64 tiles), OCEAN_GEMM_WG_CHUNK (minimum
+// development knobs (read once): OCEAN_GEMM_WG_CHUNK (minimum
 // reduction rows per block of a split row reduction), OCEAN_GEMM_WG_BIGK (row reductions at least this long use
 // 128x128 tiles), OCEAN_GEMM_WG_ATOMDIV (split limit sqrt(K / this); 0 = no limit)
-inline int small_bk() { static const int v = env_int("OCEAN_GEMM_SMALL_BK", 16) == 32 ? 32 : 16; return v; }
 inline int wg_chunk() { static const int v = env_int("OCEAN_GEMM_WG_CHUNK", 128); return v < 16 ? 16 : v; }
 inline int wg_atom_div() { static const int v = env_int("OCEAN_GEMM_WG_ATOMDIV", 2); return v; }
 inline long wg_big_k() { static const int v = env_int("OCEAN_GEMM_WG_BIGK", 8192); return v; }
@@ -634,7 +633,6 @@ int launch_mode(GemmBatch b, bool aligned, hipStream_t stream) {
     for (int q = 0; q < b.n; ++q) b.g[q].split_k = split;
   }
   if (bm == 64) {
-    if (small_bk() == 32) return launch_cfg<64, 64, 32, AKM, BKN>(b, aligned, stream);
     return launch_cfg<64, 64, 16, AKM, BKN>(b, aligned, stream);
   }
   if (bm == 128 && bn == 128) return launch_cfg<128, 128, 16, AKM, BKN>(b, aligned, stream);
