@@ -110,6 +110,134 @@ __global__ void mha3_bwd_kernel(const float* __restrict__ dOm, const float* __re
   }
 }
 
+// One wave per sample for the usual shapes (E = 64 * VEC columns, a power-of-two head count): lane l owns columns
+// l*VEC .. l*VEC+VEC-1 of every row, the 64/H lanes of a head reduce their partial dot products with xor shuffles, and
+// every load and store of a wave is one contiguous row.  (One thread per (sample, head) leaves 8192 threads on the
+// whole chip walking 128-byte strides: 33 + 53 us for a few MB.)
+template <int VEC>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  else if constexpr (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+  else { v[0] = p[0]; }
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  else if constexpr (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  else p[0] = v[0];
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void mha3_fwd_wave_kernel(const float* __restrict__ qkv, float* __restrict__ probs, float* __restrict__ o,
+                                                            int B, int H, int hlog, DropoutP dp) {
+  dp = dropout_resolve(dp);
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;                                   // wave-uniform
+  const int E = 64 * VEC, lph = 64 >> hlog, h = lane >> (6 - hlog), c = lane * VEC;
+  const float sc = 1.0f / sqrtf((float)(lph * VEC));
+  const float* base = qkv + (long)b * kTok * 3 * E + c;
+  float q[kTok][VEC], k[kTok][VEC], v[kTok][VEC];
+#pragma unroll
+  for (int i = 0; i < kTok; ++i) { ldv<VEC>(base + (long)i * 3 * E, q[i]); ldv<VEC>(base + (long)i * 3 * E + E, k[i]); ldv<VEC>(base + (long)i * 3 * E + 2 * E, v[i]); }
+  float S[kTok][kTok];
+#pragma unroll
+  for (int i = 0; i < kTok; ++i)
+#pragma unroll
+    for (int j = 0; j < kTok; ++j) {
+      float t = 0.f;
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) t = fmaf(q[i][u] * sc, k[j][u], t);
+      for (int sh = 1; sh < lph; sh <<= 1) t += __shfl_xor(t, sh);
+      S[i][j] = t;
+    }
+  const int idx = b * H + h;
+  float A[kTok][kTok];
+#pragma unroll
+  for (int i = 0; i < kTok; ++i) {
+    const float m = fmaxf(S[i][0], fmaxf(S[i][1], S[i][2]));
+    const float e0 = __expf(S[i][0] - m), e1 = __expf(S[i][1] - m), e2 = __expf(S[i][2] - m), es = e0 + e1 + e2;
+    A[i][0] = e0 / es; A[i][1] = e1 / es; A[i][2] = e2 / es;
+#pragma unroll
+    for (int j = 0; j < kTok; ++j) {
+      if ((lane & (lph - 1)) == 0) probs[((long)idx * kTok + i) * kTok + j] = A[i][j];
+      if (dp.p > 0.f) A[i][j] *= dropout_keep(dp, ((uint64_t)idx * kTok + i) * kTok + j);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kTok; ++i) {
+    float r[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) r[u] = A[i][0] * v[0][u] + A[i][1] * v[1][u] + A[i][2] * v[2][u];
+    stv<VEC>(o + ((long)b * kTok + i) * E + c, r);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void mha3_bwd_wave_kernel(const float* __restrict__ dOm, const float* __restrict__ qkv,
+                                                            const float* __restrict__ probs, float* __restrict__ dqkv, int B, int H,
+                                                            int hlog, DropoutP dp) {
+  dp = dropout_resolve(dp);
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;                                   // wave-uniform
+  const int E = 64 * VEC, lph = 64 >> hlog, h = lane >> (6 - hlog), c = lane * VEC;
+  const float sc = 1.0f / sqrtf((float)(lph * VEC));
+  const float* base = qkv + (long)b * kTok * 3 * E + c;
+  float* dbase = dqkv + (long)b * kTok * 3 * E + c;
+  const int idx = b * H + h;
+  float q[kTok][VEC], k[kTok][VEC], v[kTok][VEC], g[VEC];
+#pragma unroll
+  for (int i = 0; i < kTok; ++i) { ldv<VEC>(base + (long)i * 3 * E, q[i]); ldv<VEC>(base + (long)i * 3 * E + E, k[i]); ldv<VEC>(base + (long)i * 3 * E + 2 * E, v[i]); }
+  ldv<VEC>(dOm + (long)b * E + c, g);
+#pragma unroll
+  for (int u = 0; u < VEC; ++u) g[u] *= (1.0f / kTok);
+  float A[kTok][kTok], Ad[kTok][kTok], keep[kTok][kTok];
+#pragma unroll
+  for (int i = 0; i < kTok; ++i)
+#pragma unroll
+    for (int j = 0; j < kTok; ++j) {
+      A[i][j] = probs[((long)idx * kTok + i) * kTok + j];
+      keep[i][j] = dp.p > 0.f ? dropout_keep(dp, ((uint64_t)idx * kTok + i) * kTok + j) : 1.f;
+      Ad[i][j] = A[i][j] * keep[i][j];
+    }
+  float dv_dot[kTok];
+#pragma unroll
+  for (int j = 0; j < kTok; ++j) {
+    float t = 0.f, dv[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) { t = fmaf(g[u], v[j][u], t); dv[u] = g[u] * (Ad[0][j] + Ad[1][j] + Ad[2][j]); }
+    for (int sh = 1; sh < lph; sh <<= 1) t += __shfl_xor(t, sh);
+    dv_dot[j] = t;
+    stv<VEC>(dbase + (long)j * 3 * E + 2 * E, dv);
+  }
+  float dS[kTok][kTok];
+#pragma unroll
+  for (int i = 0; i < kTok; ++i) {
+    float dA[kTok], dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < kTok; ++j) { dA[j] = dv_dot[j] * keep[i][j]; dot += A[i][j] * dA[j]; }
+#pragma unroll
+    for (int j = 0; j < kTok; ++j) dS[i][j] = A[i][j] * (dA[j] - dot);
+  }
+#pragma unroll
+  for (int i = 0; i < kTok; ++i) {
+    float dq[VEC], dk[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      dq[u] = sc * (dS[i][0] * k[0][u] + dS[i][1] * k[1][u] + dS[i][2] * k[2][u]);
+      dk[u] = sc * (dS[0][i] * q[0][u] + dS[1][i] * q[1][u] + dS[2][i] * q[2][u]);
+    }
+    stv<VEC>(dbase + (long)i * 3 * E, dq);
+    stv<VEC>(dbase + (long)i * 3 * E + E, dk);
+  }
+}
+
+// wave-per-sample variants apply: E = 64, 128 or 256 columns and a power-of-two head count of at most 64
+inline int mha3_vec(int E, int H) {
+  if (H <= 0 || H > 64 || (H & (H - 1)) != 0) return 0;
+  return E == 256 ? 4 : E == 128 ? 2 : E == 64 ? 1 : 0;
+}
+inline int mha3_hlog(int H) { int l = 0; while ((1 << l) < H) ++l; return l; }
+
 struct FusPlan {
   int B, E, Pd;
   size_t R, lnsp, QKV, probs, O, Om, Ao, lnsa, Fn, H1, Y1, Y2, nrm, fwd_total;
@@ -191,8 +319,14 @@ int ocean_fusion_fwd(const ocean_fusion_shape* s, const float* t, const float* s
     OCEAN_TRY(l2norm_fwd(ws + pl.Y2, Pd, Zp, Pd, ws + pl.nrm, 3 * B, Pd, 1e-12f, st));
   }
   OCEAN_TRY(linear_fwd(X, E, P_[12], P_[13], ws + pl.QKV, 3 * E, 3 * B, 3 * E, E, 0, st));
-  hipLaunchKernelGGL(mha3_fwd_kernel, dim3(ceil_div((long)B * s->heads, 128)), dim3(128), 0, st, ws + pl.QKV, ws + pl.probs, ws + pl.O, B, E,
-                     s->heads, site(s, 3));
+  switch (mha3_vec(E, s->heads)) {
+    case 4: hipLaunchKernelGGL(mha3_fwd_wave_kernel<4>, dim3(ceil_div(B, 4)), dim3(256), 0, st, ws + pl.QKV, ws + pl.probs, ws + pl.O, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
+    case 2: hipLaunchKernelGGL(mha3_fwd_wave_kernel<2>, dim3(ceil_div(B, 4)), dim3(256), 0, st, ws + pl.QKV, ws + pl.probs, ws + pl.O, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
+    case 1: hipLaunchKernelGGL(mha3_fwd_wave_kernel<1>, dim3(ceil_div(B, 4)), dim3(256), 0, st, ws + pl.QKV, ws + pl.probs, ws + pl.O, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
+    default:
+      hipLaunchKernelGGL(mha3_fwd_kernel, dim3(ceil_div((long)B * s->heads, 128)), dim3(128), 0, st, ws + pl.QKV, ws + pl.probs, ws + pl.O, B, E,
+                         s->heads, site(s, 3));
+  }
   OCEAN_LAUNCH_CHECK();
   OCEAN_TRY(mean_mid(ws + pl.O, ws + pl.Om, B, kTok, E, st));
   OCEAN_TRY(linear_fwd(ws + pl.Om, E, P_[14], P_[15], ws + pl.Ao, E, B, E, E, 0, st));
@@ -223,8 +357,14 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* s
     OCEAN_TRY(lin_bwd(wf + pl.Fn, E, e2, E, B, E, E, P_[18], G_[18], G_[19], e1, E, 0, st));
     OCEAN_TRY(layernorm_bwd(e1, E, wf + pl.Ao, E, wf + pl.lnsa, P_[16], e1, E, G_[16], G_[17], B, E, none, st));
     OCEAN_TRY(lin_bwd(wf + pl.Om, E, e1, E, B, E, E, P_[14], G_[14], G_[15], wb + pl.dOm, E, 0, st));
-    hipLaunchKernelGGL(mha3_bwd_kernel, dim3(ceil_div((long)B * s->heads, 128)), dim3(128), 0, st, wb + pl.dOm, wf + pl.QKV, wf + pl.probs,
-                       wb + pl.dQKV, B, E, s->heads, site(s, 3));
+    switch (mha3_vec(E, s->heads)) {
+      case 4: hipLaunchKernelGGL(mha3_bwd_wave_kernel<4>, dim3(ceil_div(B, 4)), dim3(256), 0, st, wb + pl.dOm, wf + pl.QKV, wf + pl.probs, wb + pl.dQKV, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
+      case 2: hipLaunchKernelGGL(mha3_bwd_wave_kernel<2>, dim3(ceil_div(B, 4)), dim3(256), 0, st, wb + pl.dOm, wf + pl.QKV, wf + pl.probs, wb + pl.dQKV, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
+      case 1: hipLaunchKernelGGL(mha3_bwd_wave_kernel<1>, dim3(ceil_div(B, 4)), dim3(256), 0, st, wb + pl.dOm, wf + pl.QKV, wf + pl.probs, wb + pl.dQKV, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
+      default:
+        hipLaunchKernelGGL(mha3_bwd_kernel, dim3(ceil_div((long)B * s->heads, 128)), dim3(128), 0, st, wb + pl.dOm, wf + pl.QKV, wf + pl.probs,
+                           wb + pl.dQKV, B, E, s->heads, site(s, 3));
+    }
     OCEAN_LAUNCH_CHECK();
     OCEAN_TRY(lin_bwd(X, E, wb + pl.dQKV, 3 * E, 3 * B, 3 * E, E, P_[12], G_[12], G_[13], dX, E, 0, st));
   } else {

@@ -268,3 +268,32 @@ def test_mutual_information_estimates_match_the_per_modality_formula():
             marg = fm.mi_estimator(torch.cat([fused, m[perm]], 1))
             ref = joint.mean() - torch.log(torch.exp(marg).mean() + 1e-8)
             assert abs(got[f"{k}_mi"].item() - ref.item()) <= 1e-4 * max(1.0, abs(ref.item())), k
+
+
+@pytest.mark.parametrize("E", [64, 128, 256, 40])
+def test_fusion_token_attention_all_widths(E):
+    """GraphFusionModule (graph_fusion.py:388-473, nn.MultiheadAttention with 8 heads over the 3 modality tokens)
+    forward and input / parameter gradients against the oracle at the widths that take the wave-per-sample attention
+    kernels (64, 128, 256) and one that takes the thread-per-head kernel (40)."""
+    from ocean.models.components import GraphFusionModule
+    from oracle import ocean_ref as R
+    torch.manual_seed(5)
+    B = 7
+    m = GraphFusionModule(12, 10, 14, fusion_dim=E, projection_dim=16, dropout=0.0).eval()
+    sd = {"f." + k: v.detach().clone() for k, v in m.state_dict().items()}
+    t, s, l = torch.randn(B, 12), torch.randn(B, 10), torch.randn(B, 14)
+    w = torch.randn(B, E)
+    ref_in = [x.clone().requires_grad_(True) for x in (t, s, l)]
+    ref_sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    ref = R.fusion_forward(ref_sd, "f.", *ref_in, training=False, num_heads=8)["fused_representation"]
+    (ref * w).sum().backward()
+    m = m.cuda()
+    got_in = [x.clone().cuda().requires_grad_(True) for x in (t, s, l)]
+    got = m(*got_in, compute_contrastive_loss=False)["fused_representation"]
+    (got * w.cuda()).sum().backward()
+    close(got, ref, 1e-4)
+    for a, b in zip(got_in, ref_in):
+        close(a.grad, b.grad, 1e-3)
+    for name in ("attention_fusion.in_proj_weight", "attention_fusion.in_proj_bias", "attention_fusion.out_proj.weight",
+                 "temporal_processor.0.weight", "output_projection.3.bias"):
+        close(dict(m.named_parameters())[name].grad, ref_sd["f." + name].grad, 1e-3)
