@@ -14,6 +14,7 @@ python $R/tools/pmc_gemm.py /tmp/pmc_gemm/p_results.db > $OUT/gemm_pmc.txt
 timeout -k 10 400 python -u $R/tools/bench_configs.py 2>/dev/null > $OUT/configs.jsonl
 timeout -k 10 300 python -u $R/tools/bench_staging.py 2>/dev/null > $OUT/staging.jsonl
 timeout -k 10 300 python -u $R/tools/bench_streaming.py 2>/dev/null > $OUT/streaming.jsonl
+timeout -k 10 300 python -u $R/tools/bench_metrics.py 2>/dev/null > $OUT/metrics.jsonl
 bash $R/tools/prof_gnn.sh final/gat_instruction_mix.txt
 bash $R/tools/prof_gnn_traffic.sh final/gat_traffic.txt
 echo collected

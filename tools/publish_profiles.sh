@@ -18,5 +18,6 @@ cp $F/gemm_pmc.txt profiles/${P}_gemm_pmc.txt
 cp $F/configs.jsonl profiles/${P}_configs.jsonl
 cp $F/staging.jsonl profiles/${P}_staging.jsonl
 cp $F/streaming.jsonl profiles/${P}_streaming.jsonl
+cp $F/metrics.jsonl profiles/${P}_metrics.jsonl
 cp $F/gat_instruction_mix.txt profiles/${P}_gat_instruction_mix.txt
 cp $F/gat_traffic.txt profiles/${P}_gat_traffic.txt
