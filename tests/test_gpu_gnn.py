@@ -47,13 +47,15 @@ CASES = [  # N, G, D, H, layers, B, avg_deg
 ]
 
 
-# kernel families of the edge phase: replica-per-block with LDS tables (default where the tables fit), one node per
+# kernel families of the edge phase: replica-per-block with LDS tables (default where the tables fit; with the layer's
+# output stage applied inside the aggregate kernel or by the separate pass), one node per
 # wave with edge-parallel lanes, and the generic one-edge-at-a-time kernels (the library reads these switches per call)
-PATHS = {"replica_block": {}, "node_per_wave": {"OCEAN_GAT_NO_TILE": "1"}, "generic": {"OCEAN_GAT_GENERIC": "1"}}
+PATHS = {"replica_block": {}, "replica_block_separate_output_stage": {"OCEAN_GAT_NO_FUSED_EPI": "1"},
+         "node_per_wave": {"OCEAN_GAT_NO_TILE": "1"}, "generic": {"OCEAN_GAT_GENERIC": "1"}}
 
 
 def _select(monkeypatch, path):
-    for k in ("OCEAN_GAT_NO_TILE", "OCEAN_GAT_GENERIC"):
+    for k in ("OCEAN_GAT_NO_TILE", "OCEAN_GAT_GENERIC", "OCEAN_GAT_NO_FUSED_EPI"):
         monkeypatch.delenv(k, raising=False)
     for k, v in PATHS[path].items():
         monkeypatch.setenv(k, v)
