@@ -219,6 +219,22 @@ int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const f
                       size_t ws_bwd_floats, const float* dloss /* device scalar or NULL (=1) */, float* d_anchor /* [B,P] */,
                       float* d_positive /* [Bp,P] */, void* stream);
 
+/* The three in-batch pairs of ContrastiveLearningModule.forward in one call (graph_fusion.py:231-249 builds the pairs
+ * (temporal, spatial), (temporal, log), (spatial, log) and calls InfoNCELoss.forward, :112-162, on each).
+ * Z [3, B, P] holds the three projections; losses[q] is ACCUMULATED (+= mean over B rows) for pair q in that order.
+ * Same values as three ocean_infonce_fwd calls with K == 0, Bp == B; single-process in-batch negatives only.
+ * The forward workspace carries the state the backward call needs (it is modified by it). */
+typedef struct {
+  int B, P;
+  float tau;
+} ocean_infonce3_shape;
+size_t ocean_infonce3_workspace(const ocean_infonce3_shape* s);
+size_t ocean_infonce3_bwd_workspace(const ocean_infonce3_shape* s);
+int ocean_infonce3_fwd(const ocean_infonce3_shape* s, const float* Z, float* ws, size_t ws_floats, float* losses /* [3] */,
+                       void* stream);
+int ocean_infonce3_bwd(const ocean_infonce3_shape* s, float* ws, float* ws_bwd, size_t ws_bwd_floats,
+                       const float* dlosses /* device [3] or NULL (= 1, 1, 1) */, float* dZ /* [3, B, P] */, void* stream);
+
 /* ------------------------------------------------------------------ prediction head + sigmoid
  * Replaces prediction_head + output_activation (ocean/models/ocean_model.py:112-125, 205-206).
  * params: 0.weight [h1,E], 0.bias, 3.weight [h2,h1], 3.bias, 6.weight [S,h2], 6.bias. */

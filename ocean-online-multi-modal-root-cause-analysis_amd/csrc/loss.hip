@@ -37,12 +37,28 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a
 }
 
 // loss += sum_b (lse_b - sim[b,label_b]/tau) * inv_rows;  lse saved per row
+// group > 0: the rows are `B / group` stacked problems of `group` rows each; problem q adds into loss[q] and its row
+// r has label label0 + label_step * r
 __global__ __launch_bounds__(256) void nce_rows_fwd_kernel(const float* __restrict__ sim, int ld, int B, int K, int label0, int label_step,
                                                            float inv_tau, float inv_rows, float* __restrict__ lse_out,
-                                                           float* __restrict__ loss) {
+                                                           float* __restrict__ loss, int group) {
   __shared__ float red[kWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x * kWaves + wave;
   float contrib = 0.f;
+  if (group > 0) {
+    if (b >= B) return;
+    const float* r = sim + (long)b * ld;
+    float m = -INFINITY;
+    for (int k = lane; k < K; k += 64) m = fmaxf(m, r[k] * inv_tau);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += __expf(r[k] * inv_tau - m);
+    s = wave_sum(s);
+    const float lse = m + __logf(s);
+    const int label = label0 + label_step * (b % group);
+    if (lane == 0) { lse_out[b] = lse; unsafeAtomicAdd(loss + b / group, (lse - r[label] * inv_tau) * inv_rows); }
+    return;
+  }
   if (b < B) {
     const float* r = sim + (long)b * ld;
     float m = -INFINITY;
@@ -64,13 +80,13 @@ __global__ __launch_bounds__(256) void nce_rows_fwd_kernel(const float* __restri
 // sim[b,k] <- (softmax_k(sim/tau) - [k == label_b]) * dloss * inv_rows * inv_tau
 __global__ __launch_bounds__(256) void nce_rows_bwd_kernel(float* __restrict__ sim, int ld, int B, int K, int label0, int label_step,
                                                            float inv_tau, float inv_rows, const float* __restrict__ lse,
-                                                           const float* __restrict__ dloss) {
+                                                           const float* __restrict__ dloss, int group) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (b >= B) return;
   float* r = sim + (long)b * ld;
-  const float g = (dloss ? dloss[0] : 1.0f) * inv_rows * inv_tau;
+  const float g = (dloss ? dloss[group > 0 ? b / group : 0] : 1.0f) * inv_rows * inv_tau;
   const float l = lse[b];
-  const int label = label0 + label_step * b;
+  const int label = label0 + label_step * (group > 0 ? b % group : b);
   for (int k = lane; k < K; k += 64) r[k] = (__expf(r[k] * inv_tau - l) - (k == label ? 1.f : 0.f)) * g;
 }
 
@@ -213,13 +229,13 @@ int ocean_infonce_fwd(const ocean_infonce_shape* s, const float* anchor, const f
     g.A = ws + pl.ah; g.lda = P; g.B = ws + pl.nh; g.ldb = P; g.C = ws + pl.sim + 4; g.ldc = pl.ldsim; g.M = B; g.N = K; g.K = P;
     OCEAN_TRY(ocean_launch_gemm(g, st));
     hipLaunchKernelGGL(nce_rows_fwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.sim + 3, pl.ldsim, B, K + 1, 0, 0, inv_tau,
-                       inv_rows, ws + pl.lse, loss);
+                       inv_rows, ws + pl.lse, loss, 0);
   } else {
     GemmP g = gemm_defaults();
     g.A = ws + pl.ah; g.lda = P; g.B = ws + pl.ph; g.ldb = P; g.C = ws + pl.sim; g.ldc = pl.ldsim; g.M = B; g.N = s->Bp; g.K = P;
     OCEAN_TRY(ocean_launch_gemm(g, st));
     hipLaunchKernelGGL(nce_rows_fwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.sim, pl.ldsim, B, s->Bp, s->label_offset, 1,
-                       inv_tau, inv_rows, ws + pl.lse, loss);
+                       inv_tau, inv_rows, ws + pl.lse, loss, 0);
   }
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
@@ -238,7 +254,7 @@ int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const f
   if (K > 0) {
     float* sim = ws + pl.sim + 3;
     hipLaunchKernelGGL(nce_rows_bwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, sim, pl.ldsim, B, K + 1, 0, 0, inv_tau, inv_rows,
-                       ws + pl.lse, dloss);
+                       ws + pl.lse, dloss, 0);
     OCEAN_LAUNCH_CHECK();
     // d a_hat = dL[:,0] * p_hat + dL[:,1:] . n_hat ;  d p_hat = dL[:,0] * a_hat
     OCEAN_TRY(linear_bwd_data(sim + 1, pl.ldsim, ws + pl.nh, dah, P, B, K, P, 0, st));
@@ -249,7 +265,7 @@ int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const f
   } else {
     float* sim = ws + pl.sim;
     hipLaunchKernelGGL(nce_rows_bwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, sim, pl.ldsim, B, Bp, s->label_offset, 1, inv_tau,
-                       inv_rows, ws + pl.lse, dloss);
+                       inv_rows, ws + pl.lse, dloss, 0);
     OCEAN_LAUNCH_CHECK();
     OCEAN_TRY(linear_bwd_data(sim, pl.ldsim, ws + pl.ph, dah, P, B, Bp, P, 0, st));      // [B,Bp] . [Bp,P]
     OCEAN_TRY(zero_f32(dph, (size_t)Bp * P, st));
@@ -257,6 +273,87 @@ int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const f
   }
   OCEAN_TRY(l2norm_bwd(dah, P, ws + pl.ah, P, ws + pl.na, d_anchor, P, B, P, 1e-12f, st));
   OCEAN_TRY(l2norm_bwd(dph, P, ws + pl.ph, P, ws + pl.np, d_positive, P, Bp, P, 1e-12f, st));
+  return OCEAN_OK;
+}
+
+// ---------------------------------------------------------------- the three in-batch pairs at once
+// Z [3, B, P]: the three modality projections.  Pair q of {(0,1), (0,2), (1,2)} takes rows of Z[a] as anchors and rows
+// of Z[b] as positives.  Every projection is re-normalised once (InfoNCELoss does it per call, with the same result),
+// the three similarity matrices come from one batched GEMM launch, and one row kernel finishes all three losses.
+namespace {
+struct Nce3Plan { size_t zh, nrm, sim, lse, total; };
+int nce3_plan(const ocean_infonce3_shape* s, Nce3Plan* p) {
+  if (!s) return OCEAN_ERR_NULL;
+  if (s->B <= 0 || s->P <= 0 || !(s->tau > 0.f)) return OCEAN_ERR_BAD_SHAPE;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o = al4(o + n); return r; };
+  p->zh = take((size_t)3 * s->B * s->P); p->nrm = take((size_t)3 * s->B);
+  p->sim = take((size_t)3 * s->B * s->B); p->lse = take((size_t)3 * s->B);
+  p->total = o;
+  return OCEAN_OK;
+}
+constexpr int kPairA[3] = {0, 0, 1}, kPairB[3] = {1, 2, 2};
+}  // namespace
+
+size_t ocean_infonce3_workspace(const ocean_infonce3_shape* s) { Nce3Plan p; return nce3_plan(s, &p) == OCEAN_OK ? p.total : 0; }
+size_t ocean_infonce3_bwd_workspace(const ocean_infonce3_shape* s) { return s ? al4((size_t)3 * s->B * s->P) : 0; }
+
+int ocean_infonce3_fwd(const ocean_infonce3_shape* s, const float* Z, float* ws, size_t ws_floats, float* losses, void* stream) {
+  Nce3Plan pl;
+  OCEAN_TRY(nce3_plan(s, &pl));
+  if (!Z || !ws || !losses) return OCEAN_ERR_NULL;
+  if (ws_floats < pl.total) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, P = s->P;
+  const size_t BP = (size_t)B * P, BB = (size_t)B * B;
+  OCEAN_TRY(l2norm_fwd(Z, P, ws + pl.zh, P, ws + pl.nrm, 3 * B, P, 1e-12f, st));
+  GemmP g[3];
+  for (int q = 0; q < 3; ++q) {
+    g[q] = gemm_defaults();
+    g[q].A = ws + pl.zh + kPairA[q] * BP; g[q].lda = P; g[q].B = ws + pl.zh + kPairB[q] * BP; g[q].ldb = P;
+    g[q].C = ws + pl.sim + q * BB; g[q].ldc = B; g[q].M = B; g[q].N = B; g[q].K = P;
+  }
+  OCEAN_TRY(ocean_launch_gemm_batch(g, 3, st));
+  hipLaunchKernelGGL(nce_rows_fwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, ws + pl.sim, B, 3 * B, B, 0, 1, 1.0f / s->tau,
+                     1.0f / (float)B, ws + pl.lse, losses, B);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int ocean_infonce3_bwd(const ocean_infonce3_shape* s, float* ws, float* wb, size_t wb_floats, const float* dlosses, float* dZ,
+                       void* stream) {
+  Nce3Plan pl;
+  OCEAN_TRY(nce3_plan(s, &pl));
+  if (!ws || !wb || !dZ) return OCEAN_ERR_NULL;
+  if (wb_floats < ocean_infonce3_bwd_workspace(s)) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, P = s->P;
+  const size_t BP = (size_t)B * P, BB = (size_t)B * B;
+  float* sim = ws + pl.sim; float* zh = ws + pl.zh; float* dzh = wb;
+  hipLaunchKernelGGL(nce_rows_bwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, sim, B, 3 * B, B, 0, 1, 1.0f / s->tau, 1.0f / (float)B,
+                     ws + pl.lse, dlosses, B);
+  OCEAN_LAUNCH_CHECK();
+  // anchors: d zh[a] (+)= G_q . zh[b]   (G_q = the rewritten similarity matrix of pair q)
+  GemmP g[3];
+  for (int q = 0; q < 3; ++q) {
+    g[q] = gemm_defaults();
+    g[q].A = sim + q * BB; g[q].lda = B; g[q].B = zh + kPairB[q] * BP; g[q].ldb = P; g[q].b_kn = 1;
+    g[q].C = dzh + kPairA[q] * BP; g[q].ldc = P; g[q].M = B; g[q].N = P; g[q].K = B;
+  }
+  GemmP first[2] = {g[0], g[2]};                       // pairs (0,1) and (1,2) write d zh[0] and d zh[1]
+  OCEAN_TRY(ocean_launch_gemm_batch(first, 2, st));
+  g[1].R = g[1].C; g[1].ldr = P;                       // pair (0,2) adds to d zh[0]
+  OCEAN_TRY(ocean_launch_gemm(g[1], st));
+  // positives: d zh[b] += G_q^T . zh[a]  (row reductions: they accumulate with atomics, so two may share an output)
+  OCEAN_TRY(zero_f32(dzh + 2 * BP, BP, st));
+  GemmP t[3];
+  for (int q = 0; q < 3; ++q) {
+    t[q] = gemm_defaults();
+    t[q].A = sim + q * BB; t[q].lda = B; t[q].a_kmajor = 1; t[q].B = zh + kPairA[q] * BP; t[q].ldb = P; t[q].b_kn = 1;
+    t[q].C = dzh + kPairB[q] * BP; t[q].ldc = P; t[q].M = B; t[q].N = P; t[q].K = B; t[q].split_k = 0;
+  }
+  OCEAN_TRY(ocean_launch_gemm_batch(t, 3, st));
+  OCEAN_TRY(l2norm_bwd(dzh, P, zh, P, ws + pl.nrm, dZ, P, 3 * B, P, 1e-12f, st));
   return OCEAN_OK;
 }
 

@@ -79,6 +79,10 @@ class InfoNceShape(ctypes.Structure):
                 ("mean_rows", c_int), ("tau", c_float)]
 
 
+class InfoNce3Shape(ctypes.Structure):
+    _fields_ = [("B", c_int), ("P", c_int), ("tau", c_float)]
+
+
 class HeadShape(ctypes.Structure):
     _fields_ = [("B", c_int), ("E", c_int), ("h1", c_int), ("h2", c_int), ("S", c_int), ("training", c_int),
                 ("dropout", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
@@ -109,6 +113,11 @@ def _declare_rest(lib) -> None:
     sig("ocean_infonce_bwd_workspace", c_size_t, ip)
     sig("ocean_infonce_fwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp)
     sig("ocean_infonce_bwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp, vp, vp)
+    i3 = ctypes.POINTER(InfoNce3Shape)
+    sig("ocean_infonce3_workspace", c_size_t, i3)
+    sig("ocean_infonce3_bwd_workspace", c_size_t, i3)
+    sig("ocean_infonce3_fwd", c_int, i3, vp, vp, c_size_t, vp, vp)
+    sig("ocean_infonce3_bwd", c_int, i3, vp, vp, c_size_t, vp, vp, vp)
     sig("ocean_head_workspace", c_size_t, hp)
     sig("ocean_head_bwd_workspace", c_size_t, hp)
     sig("ocean_head_fwd", c_int, hp, vp, tp, vp, c_size_t, vp, vp, vp)

@@ -14,6 +14,8 @@ reference raises as soon as ptr + 3B > 2*16, graph_fusion.py:263-273), and
 """
 from __future__ import annotations
 
+import os
+
 import ctypes
 from typing import Any, Callable, Dict, Optional
 
@@ -74,6 +76,7 @@ class ContrastiveLearningModule(nn.Module):
         self.gather_positives: Optional[Callable[[torch.Tensor], torch.Tensor]] = None
         self.rank_row_offset: Callable[[int], int] = lambda local_rows: 0
         self._ptr_host: Optional[int] = None       # host shadow of memory_ptr (avoids a device read per step)
+        self.batch_pairs = os.environ.get("OCEAN_INFONCE_PER_PAIR") != "1"     # measurement switch: one call per pair
 
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
@@ -82,10 +85,19 @@ class ContrastiveLearningModule(nn.Module):
     def _get_negatives(self) -> torch.Tensor:
         return self.memory_bank.clone().detach()
 
-    def losses_from_projections(self, projections: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    def losses_from_projections(self, projections: Dict[str, torch.Tensor],
+                                stacked: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """InfoNCE over every pair of modalities (graph_fusion.py:231-249).  `stacked` ([3, B, P], the same three
+        projections in dictionary order, as the fused driver produces them) lets the single-process in-batch case run
+        the three pairs as one batched call."""
         names = list(projections.keys())
         losses = {}
         neg = self._get_negatives() if self.negatives == "bank" else None
+        if (neg is None and self.gather_positives is None and stacked is not None and len(names) == 3 and stacked.shape[0] == 3
+                and self.batch_pairs):
+            three = ops.infonce_pairs(stacked, self.infonce_loss.temperature).unbind(0)   # one backward node for the three scalars
+            pairs = [(a, b) for i, a in enumerate(names) for b in names[i + 1:]]
+            return {f"{a}_{b}_contrastive": three[q] for q, (a, b) in enumerate(pairs)}
         gathered = {}
         if neg is None and self.gather_positives is not None and len(names) > 1:
             # data parallel: every modality but the first serves as the positive side of some pair; one collective
@@ -243,7 +255,7 @@ class GraphFusionModule(nn.Module):
         if compute_contrastive_loss:
             cm = self.contrastive_module
             projections = {"temporal": Zp[0], "spatial": Zp[1], "log": Zp[2]}
-            results["contrastive_losses"] = cm.losses_from_projections(projections)
+            results["contrastive_losses"] = cm.losses_from_projections(projections, stacked=Zp)
             if cm.training and cm.negatives == "bank":
                 cm._update_memory_bank(projections)
             results["projections"] = projections

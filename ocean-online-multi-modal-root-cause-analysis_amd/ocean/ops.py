@@ -60,6 +60,44 @@ def infonce(anchor: torch.Tensor, positive: torch.Tensor, negatives: Optional[to
                           int(label_offset), int(mean_rows))
 
 
+class _InfoNce3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Z, tau):
+        L = _hip.lib()
+        sh = _hip.InfoNce3Shape()
+        _, sh.B, sh.P = Z.shape
+        sh.tau = tau
+        ws = torch.empty(L.ocean_infonce3_workspace(ctypes.byref(sh)), device=Z.device, dtype=torch.float32)
+        losses = torch.zeros(3, device=Z.device, dtype=torch.float32)
+        _hip.check(L.ocean_infonce3_fwd(ctypes.byref(sh), _hip.dev_ptr(Z, "projections"), _hip.dev_ptr(ws), ws.numel(),
+                                        _hip.dev_ptr(losses), _hip.stream()), "ocean_infonce3_fwd")
+        ctx.sh = sh
+        ctx.save_for_backward(ws)
+        ctx.shape = Z.shape
+        return losses
+
+    @staticmethod
+    def backward(ctx, dlosses):
+        L = _hip.lib()
+        (ws,) = ctx.saved_tensors
+        sh = ctx.sh
+        wb = torch.empty(L.ocean_infonce3_bwd_workspace(ctypes.byref(sh)), device=ws.device, dtype=torch.float32)
+        dZ = torch.empty(ctx.shape, device=ws.device, dtype=torch.float32)
+        _hip.check(L.ocean_infonce3_bwd(ctypes.byref(sh), _hip.dev_ptr(ws), _hip.dev_ptr(wb), wb.numel(),
+                                        _hip.dev_ptr(dlosses.contiguous().float(), "dlosses"), _hip.dev_ptr(dZ), _hip.stream()),
+                   "ocean_infonce3_bwd")
+        return dZ, None
+
+
+def infonce_pairs(projections: torch.Tensor, temperature: float = 0.1) -> torch.Tensor:
+    """The in-batch InfoNCE losses of the pairs (0,1), (0,2), (1,2) of `projections` [3, B, P] as one [3] tensor: what
+    three InfoNCELoss.forward(anchor, positive) calls return (graph_fusion.py:112-162, 231-249), from one normalisation,
+    one batched similarity launch and one row pass.  The backward pass consumes the saved state: differentiate once."""
+    if projections.dim() != 3 or projections.shape[0] != 3:
+        raise ValueError("projections must be [3, B, dim]")
+    return _InfoNce3.apply(projections.contiguous().float(), float(temperature))
+
+
 class _Bce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, probs, targets, mean_n):

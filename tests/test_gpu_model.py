@@ -297,3 +297,28 @@ def test_fusion_token_attention_all_widths(E):
     for name in ("attention_fusion.in_proj_weight", "attention_fusion.in_proj_bias", "attention_fusion.out_proj.weight",
                  "temporal_processor.0.weight", "output_projection.3.bias"):
         close(dict(m.named_parameters())[name].grad, ref_sd["f." + name].grad, 1e-3)
+
+
+@pytest.mark.parametrize("B,P", [(5, 16), (64, 128), (130, 24)])
+def test_three_pair_infonce_equals_three_single_calls_and_the_oracle(B, P):
+    """InfoNCELoss.forward on the pairs (temporal, spatial), (temporal, log), (spatial, log) (graph_fusion.py:112-162,
+    231-249): the batched entry point against the oracle and against the per-pair entry point, values and gradients,
+    with unequal weights on the three losses."""
+    from ocean import ops
+    from oracle import ocean_ref as R
+    g = torch.Generator().manual_seed(B)
+    Z = torch.randn(3, B, P, generator=g) * torch.rand(3, B, 1, generator=g).add(0.5)      # not unit rows: the op re-normalises
+    w = torch.tensor([1.0, 0.3, -2.0])
+    zr = Z.clone().requires_grad_(True)
+    ref = torch.stack([R.infonce(zr[a], zr[b], None, 0.1) for a, b in ((0, 1), (0, 2), (1, 2))])
+    (ref * w).sum().backward()
+    zg = Z.clone().cuda().requires_grad_(True)
+    got = ops.infonce_pairs(zg, 0.1)
+    (got * w.cuda()).sum().backward()
+    close(got, ref, 1e-5)
+    close(zg.grad, zr.grad, 1e-3)
+    zs = Z.clone().cuda().requires_grad_(True)
+    single = torch.stack([ops.infonce(zs[a], zs[b], None, 0.1) for a, b in ((0, 1), (0, 2), (1, 2))])
+    (single * w.cuda()).sum().backward()
+    close(got, single, 1e-6)
+    close(zg.grad, zs.grad, 1e-4)
