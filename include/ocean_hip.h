@@ -235,6 +235,19 @@ int ocean_infonce3_fwd(const ocean_infonce3_shape* s, const float* Z, float* ws,
 int ocean_infonce3_bwd(const ocean_infonce3_shape* s, float* ws, float* ws_bwd, size_t ws_bwd_floats,
                        const float* dlosses /* device [3] or NULL (= 1, 1, 1) */, float* dZ /* [3, B, P] */, void* stream);
 
+/* MINE estimates of GraphFusionModule._compute_mutual_information (graph_fusion.py:475-501) for the three modalities:
+ * mi[m] = mean_b f(cat(fused_b, X_{b,m})) - log(mean_b exp f(cat(fused_b, X_{perms[m][b],m})) + 1e-8),
+ * f = Linear(E -> 1)(ReLU(Linear(2E -> E)(.))) with weights w0 [E, 2E], b0 [E], w1 [E], b1 [1].
+ * X is [B, 3, E] (the processed temporal / spatial / log features side by side), perms [3, B] int64 row permutations
+ * drawn by the caller.  Diagnostics only: no gradient. */
+typedef struct {
+  int B, E;
+} ocean_mi_shape;
+size_t ocean_mi_workspace(const ocean_mi_shape* s);
+int ocean_mi_estimates(const ocean_mi_shape* s, const float* fused, const float* X, const long long* perms, const float* w0,
+                       const float* b0, const float* w1, const float* b1, float* ws, size_t ws_floats, float* mi /* [3] */,
+                       void* stream);
+
 /* ------------------------------------------------------------------ prediction head + sigmoid
  * Replaces prediction_head + output_activation (ocean/models/ocean_model.py:112-125, 205-206).
  * params: 0.weight [h1,E], 0.bias, 3.weight [h2,h1], 3.bias, 6.weight [S,h2], 6.bias. */

@@ -45,20 +45,6 @@ __global__ __launch_bounds__(256) void nce_rows_fwd_kernel(const float* __restri
   __shared__ float red[kWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x * kWaves + wave;
   float contrib = 0.f;
-  if (group > 0) {
-    if (b >= B) return;
-    const float* r = sim + (long)b * ld;
-    float m = -INFINITY;
-    for (int k = lane; k < K; k += 64) m = fmaxf(m, r[k] * inv_tau);
-    m = wave_max(m);
-    float s = 0.f;
-    for (int k = lane; k < K; k += 64) s += __expf(r[k] * inv_tau - m);
-    s = wave_sum(s);
-    const float lse = m + __logf(s);
-    const int label = label0 + label_step * (b % group);
-    if (lane == 0) { lse_out[b] = lse; unsafeAtomicAdd(loss + b / group, (lse - r[label] * inv_tau) * inv_rows); }
-    return;
-  }
   if (b < B) {
     const float* r = sim + (long)b * ld;
     float m = -INFINITY;
@@ -68,13 +54,20 @@ __global__ __launch_bounds__(256) void nce_rows_fwd_kernel(const float* __restri
     for (int k = lane; k < K; k += 64) s += __expf(r[k] * inv_tau - m);
     s = wave_sum(s);
     const float lse = m + __logf(s);
-    const int label = label0 + label_step * b;
+    const int label = label0 + label_step * (group > 0 ? b % group : b);
     contrib = (lse - r[label] * inv_tau) * inv_rows;
     if (lane == 0) lse_out[b] = lse;
   }
   if (lane == 0) red[wave] = contrib;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+  // one add per block (same-address atomics serialise: one per row cost 46 us at 3 x 1024 rows); a block whose rows
+  // straddle two stacked problems adds per wave instead
+  const int b0 = blockIdx.x * kWaves, b1 = min(b0 + kWaves, B) - 1;
+  if (group <= 0 || b0 / group == b1 / group) {
+    if (threadIdx.x == 0) unsafeAtomicAdd(loss + (group > 0 ? b0 / group : 0), red[0] + red[1] + red[2] + red[3]);
+  } else if (lane == 0 && b < B) {
+    unsafeAtomicAdd(loss + b / group, contrib);
+  }
 }
 
 // sim[b,k] <- (softmax_k(sim/tau) - [k == label_b]) * dloss * inv_rows * inv_tau
@@ -354,6 +347,80 @@ int ocean_infonce3_bwd(const ocean_infonce3_shape* s, float* ws, float* wb, size
   }
   OCEAN_TRY(ocean_launch_gemm_batch(t, 3, st));
   OCEAN_TRY(l2norm_bwd(dzh, P, zh, P, ws + pl.nrm, dZ, P, 3 * B, P, 1e-12f, st));
+  return OCEAN_OK;
+}
+
+// ---------------------------------------------------------------- mutual-information estimates
+// f(cat(fused, x)) = w1 . relu(W0a fused + W0b x + b0) + b1 with W0 = [W0a | W0b]: the fused half U = fused W0a^T is
+// shared by all six score sets (3 modalities x joint / shuffled), the modality half V_m = X_m W0b^T by a modality's
+// joint and shuffled rows, so two small GEMM launches replace the reference's [6B, 2E] x [2E, E] product over
+// materialised concatenations, and one row kernel forms both scores of a (modality, row).
+namespace {
+__global__ __launch_bounds__(256) void mi_rows_kernel(const float* __restrict__ U, const float* __restrict__ V, const long long* __restrict__ perms,
+                                                      const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      float* __restrict__ acc, int B, int E) {
+  __shared__ float red[2][kWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, idx = blockIdx.x * kWaves + wave;
+  float joint = 0.f, marg = 0.f;
+  if (idx < 3 * B) {
+    const int m = idx / B, b = idx % B;
+    const long pb = perms[idx];
+    const float* u = U + (long)b * E;
+    const float* vj = V + ((long)m * B + b) * E;
+    const float* vm = V + ((long)m * B + pb) * E;
+    float hj = 0.f, hm = 0.f;
+    for (int c = lane; c < E; c += 64) {
+      const float base = u[c] + b0[c], w = w1[c];
+      hj = fmaf(fmaxf(base + vj[c], 0.f), w, hj);
+      hm = fmaf(fmaxf(base + vm[c], 0.f), w, hm);
+    }
+    joint = wave_sum(hj) + b1[0];
+    marg = __expf(wave_sum(hm) + b1[0]);
+  }
+  if (lane == 0) { red[0][wave] = joint; red[1][wave] = marg; }
+  __syncthreads();
+  const int i0 = blockIdx.x * kWaves, i1 = min(i0 + kWaves, 3 * B) - 1;
+  if (i0 / B == i1 / B) {           // the block's rows belong to one modality: one pair of adds
+    if (threadIdx.x < 2) unsafeAtomicAdd(acc + 2 * (i0 / B) + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+  } else if (lane == 0 && idx < 3 * B) {
+    unsafeAtomicAdd(acc + 2 * (idx / B), joint);
+    unsafeAtomicAdd(acc + 2 * (idx / B) + 1, marg);
+  }
+}
+// mi[m] = mean(joint scores) - log(mean(exp(shuffled scores)) + 1e-8)      (graph_fusion.py:497-499)
+__global__ void mi_finish_kernel(const float* __restrict__ acc, float* __restrict__ mi, int B) {
+  const int m = threadIdx.x;
+  if (m < 3) mi[m] = acc[2 * m] / (float)B - __logf(acc[2 * m + 1] / (float)B + 1e-8f);
+}
+}  // namespace
+
+size_t ocean_mi_workspace(const ocean_mi_shape* s) {
+  return s && s->B > 0 && s->E > 0 ? al4((size_t)s->B * s->E) + al4((size_t)3 * s->B * s->E) + 8 : 0;
+}
+
+int ocean_mi_estimates(const ocean_mi_shape* s, const float* fused, const float* X, const long long* perms, const float* w0,
+                       const float* b0, const float* w1, const float* b1, float* ws, size_t ws_floats, float* mi, void* stream) {
+  if (!s || !fused || !X || !perms || !w0 || !b0 || !w1 || !b1 || !ws || !mi) return OCEAN_ERR_NULL;
+  if (s->B <= 0 || s->E <= 0) return OCEAN_ERR_BAD_SHAPE;
+  if (ws_floats < ocean_mi_workspace(s)) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = s->B, E = s->E;
+  float* U = ws; float* V = U + al4((size_t)B * E); float* acc = V + al4((size_t)3 * B * E);
+  OCEAN_TRY(zero_f32(acc, 8, st));
+  GemmP u = gemm_defaults();
+  u.A = fused; u.lda = E; u.B = w0; u.ldb = 2 * E; u.C = U; u.ldc = E; u.M = B; u.N = E; u.K = E;
+  OCEAN_TRY(ocean_launch_gemm(u, st));
+  GemmP v[3];
+  for (int m = 0; m < 3; ++m) {
+    v[m] = gemm_defaults();
+    v[m].A = X + (size_t)m * E; v[m].lda = 3 * E; v[m].B = w0 + E; v[m].ldb = 2 * E;
+    v[m].C = V + (size_t)m * B * E; v[m].ldc = E; v[m].M = B; v[m].N = E; v[m].K = E;
+  }
+  OCEAN_TRY(ocean_launch_gemm_batch(v, 3, st));
+  hipLaunchKernelGGL(mi_rows_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, U, V, perms, b0, w1, b1, acc, B, E);
+  OCEAN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mi_finish_kernel, dim3(1), dim3(64), 0, st, acc, mi, B);
+  OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }
 

@@ -83,6 +83,10 @@ class InfoNce3Shape(ctypes.Structure):
     _fields_ = [("B", c_int), ("P", c_int), ("tau", c_float)]
 
 
+class MiShape(ctypes.Structure):
+    _fields_ = [("B", c_int), ("E", c_int)]
+
+
 class HeadShape(ctypes.Structure):
     _fields_ = [("B", c_int), ("E", c_int), ("h1", c_int), ("h2", c_int), ("S", c_int), ("training", c_int),
                 ("dropout", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
@@ -118,6 +122,9 @@ def _declare_rest(lib) -> None:
     sig("ocean_infonce3_bwd_workspace", c_size_t, i3)
     sig("ocean_infonce3_fwd", c_int, i3, vp, vp, c_size_t, vp, vp)
     sig("ocean_infonce3_bwd", c_int, i3, vp, vp, c_size_t, vp, vp, vp)
+    mp = ctypes.POINTER(MiShape)
+    sig("ocean_mi_workspace", c_size_t, mp)
+    sig("ocean_mi_estimates", c_int, mp, vp, vp, vp, vp, vp, vp, vp, vp, c_size_t, vp, vp)
     sig("ocean_head_workspace", c_size_t, hp)
     sig("ocean_head_bwd_workspace", c_size_t, hp)
     sig("ocean_head_fwd", c_int, hp, vp, tp, vp, c_size_t, vp, vp, vp)

@@ -262,26 +262,32 @@ class GraphFusionModule(nn.Module):
             results["mutual_information"] = self._mutual_information(fused, X) if self.compute_mutual_information else {}
         return results
 
-    def _mutual_information(self, fused, X) -> Dict[str, torch.Tensor]:
+    @staticmethod
+    def draw_permutations(B: int, device) -> torch.Tensor:
+        """Three independent uniform row permutations [3, B] (the reference draws torch.randperm(B) once per modality,
+        graph_fusion.py:489): the order of one row of uniform random keys each, in one draw and one sort."""
+        return torch.rand(3, B, device=device).argsort(dim=1)
+
+    def _mutual_information(self, fused, X, perms: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """MINE estimates of graph_fusion.py:475-501 (diagnostics only: they enter no loss).  X is [B, 3, E], the
-        processed temporal / spatial / log features.  The three modalities go through the estimator as one
-        [6B, 2E] batch; the three permutations are still drawn one after the other, as the reference draws them."""
-        w0, b0, w1, b1 = (p.detach() for p in (self.mi_estimator[0].weight, self.mi_estimator[0].bias,
-                                               self.mi_estimator[2].weight, self.mi_estimator[2].bias))
+        processed temporal / spatial / log features; perms [3, B] are the shuffles of the marginal term."""
+        w0, b0, w1, b1 = (p.detach().contiguous() for p in (self.mi_estimator[0].weight, self.mi_estimator[0].bias,
+                                                            self.mi_estimator[2].weight, self.mi_estimator[2].bias))
         B, E = fused.shape
         with torch.no_grad():
             dev = fused.device
-            perms = torch.stack([torch.randperm(B, device=dev) for _ in range(3)])            # [3, B]
-            m = X.detach().permute(1, 0, 2)                                                    # [3, B, E]
-            shuffled = m[torch.arange(3, device=dev)[:, None], perms]                          # [3, B, E]
-            left = fused.detach().unsqueeze(0).expand(3, B, E).repeat(1, 2, 1)                 # [3, 2B, E]: joint rows, marginal rows
-            pairs = torch.cat([left, torch.cat([m, shuffled], 1)], 2).reshape(6 * B, 2 * E)
-            hid = torch.empty(6 * B, E, device=dev)
-            _hip.gemm(pairs, w0, hid, 6 * B, E, 2 * E, bias=b0, relu=True)
-            sc = torch.empty(6 * B, 1, device=dev)
-            _hip.gemm(hid, w1, sc, 6 * B, 1, E, bias=b1)
-            sc = sc.view(3, 2, B)
-            mi = sc[:, 0].mean(1) - torch.log(torch.exp(sc[:, 1]).mean(1) + 1e-8)
+            if perms is None:
+                perms = self.draw_permutations(B, dev)
+            perms = perms.to(device=dev, dtype=torch.long).contiguous()
+            L = _hip.lib()
+            sh = _hip.MiShape()
+            sh.B, sh.E = B, E
+            ws = torch.empty(L.ocean_mi_workspace(ctypes.byref(sh)), device=dev, dtype=torch.float32)
+            mi = torch.empty(3, device=dev, dtype=torch.float32)
+            _hip.check(L.ocean_mi_estimates(ctypes.byref(sh), _hip.dev_ptr(fused.detach().contiguous(), "fused"),
+                                            _hip.dev_ptr(X.detach().contiguous(), "processed"), ctypes.c_void_p(perms.data_ptr()),
+                                            _hip.dev_ptr(w0), _hip.dev_ptr(b0), _hip.dev_ptr(w1), _hip.dev_ptr(b1),
+                                            _hip.dev_ptr(ws), ws.numel(), _hip.dev_ptr(mi), _hip.stream()), "ocean_mi_estimates")
         return {f"{k}_mi": mi[i] for i, k in enumerate(("temporal", "spatial", "log"))}
 
     def get_fusion_analysis(self, temporal_features, spatial_features, log_features) -> Dict[str, Any]:

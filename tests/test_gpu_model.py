@@ -246,28 +246,29 @@ def test_dropout_backward_matches_finite_differences(golden, neg):
         assert abs(numeric - analytic) <= 6e-2 * abs(analytic) + 2e-3, (k, numeric, analytic)
 
 
-def test_mutual_information_estimates_match_the_per_modality_formula():
-    """The three MINE estimates are computed as one batch; each must equal the reference's per-modality expression
+@pytest.mark.parametrize("B,E", [(12, 32), (130, 256), (5, 40)])
+def test_mutual_information_estimates_match_the_per_modality_formula(B, E):
+    """The three MINE estimates come from one fused call; each must equal the reference's per-modality expression
     mean(f(cat(out, m))) - log(mean(exp(f(cat(out, m[perm])))) + 1e-8) (graph_fusion.py:475-501) under the same
-    three permutation draws."""
-    import ocean
+    three permutations."""
     from ocean.models.components import GraphFusionModule
     torch.manual_seed(5)
-    fm = GraphFusionModule(16, 16, 16, fusion_dim=32, projection_dim=16).cuda().train()
-    B, E = 12, 32
+    fm = GraphFusionModule(16, 16, 16, fusion_dim=E, projection_dim=16).cuda().train()
     fused = torch.randn(B, E, device="cuda")
     X = torch.randn(B, 3, E, device="cuda")
-    torch.manual_seed(123)
-    got = fm._mutual_information(fused, X)
-    torch.manual_seed(123)
+    perms = GraphFusionModule.draw_permutations(B, "cuda")
+    assert perms.shape == (3, B) and all(sorted(p.tolist()) == list(range(B)) for p in perms)
+    got = fm._mutual_information(fused, X, perms)
     with torch.no_grad():
         for i, k in enumerate(("temporal", "spatial", "log")):
-            perm = torch.randperm(B, device="cuda")
             m = X[:, i]
             joint = fm.mi_estimator(torch.cat([fused, m], 1))
-            marg = fm.mi_estimator(torch.cat([fused, m[perm]], 1))
+            marg = fm.mi_estimator(torch.cat([fused, m[perms[i]]], 1))
             ref = joint.mean() - torch.log(torch.exp(marg).mean() + 1e-8)
             assert abs(got[f"{k}_mi"].item() - ref.item()) <= 1e-4 * max(1.0, abs(ref.item())), k
+    # without explicit permutations a fresh draw is used each call
+    a, b = fm._mutual_information(fused, X), fm._mutual_information(fused, X)
+    assert all(torch.isfinite(v) for v in a.values()) and any(a[k].item() != b[k].item() for k in a)
 
 
 @pytest.mark.parametrize("E", [64, 128, 256, 40])

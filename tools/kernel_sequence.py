@@ -12,6 +12,7 @@ marks = [i for i, r in enumerate(rows) if "clip_adam" in r[0]]
 lo, hi = marks[which - 1] + 1, marks[which] + 1
 prev_end = rows[lo - 1][2]
 for name, start, end, gx in rows[lo:hi]:
-    short = name.split("(")[0][-70:]
+    short = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "")
+    short = short.split("(")[0][:90].replace(" ", "")
     print(f"{(start - prev_end) / 1000.0:7.1f} gap {(end - start) / 1000.0:8.1f} us  grid {gx:8d}  {short}")
     prev_end = end
