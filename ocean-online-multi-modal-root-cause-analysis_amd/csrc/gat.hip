@@ -770,12 +770,17 @@ __device__ __forceinline__ void block_channel_sums(const float (&v)[CPL], float*
   __syncthreads();
 }
 
-__global__ void fold_slots_kernel(const float* __restrict__ slots, float* __restrict__ dst, int n) {
+// up to three slot sets per launch (blockIdx.y): a layer's bias and two attention-vector gradients fold together
+struct FoldSet { const float* slots; float* dst; int n; };
+struct FoldBatch { FoldSet s[3]; };
+__global__ void fold_slots_kernel(const FoldBatch b) {
+  const FoldSet f = b.s[blockIdx.y];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+  if (c >= f.n) return;
   float t = 0.f;
-  for (int q = 0; q < kSumSlots; ++q) t += slots[(size_t)q * n + c];
-  dst[c] += t;
+#pragma unroll 8
+  for (int q = 0; q < kSumSlots; ++q) t += f.slots[(size_t)q * f.n + c];
+  f.dst[c] += t;
 }
 
 // a_s / a_d of every row (same result as gat_scores_kernel)
@@ -1359,8 +1364,6 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
       GAT_STREAM_FAST(gat_bwd_prep_fast_kernel, last ? wb + pl.dpool : wb + pl.dY, last ? pl.pool_n : 0,
                       last ? 1.0f / (float)pl.pool_n : 1.0f, wf + pl.agg[l], params[pg_layer(l, 3)], wb + pl.dagg, wb + pl.Dn,
                       slot_b, pl.concat[l], feat_drop(s, l));
-      hipLaunchKernelGGL(fold_slots_kernel, dim3(ceil_div(od, 64)), dim3(64), 0, st, slot_b, grads[pg_layer(l, 3)], od);
-      OCEAN_LAUNCH_CHECK();
     } else {
       hipLaunchKernelGGL(gat_bwd_epilogue_kernel, dim3(egrid(rows * od)), dim3(256), 0, st, last ? wb + pl.dpool : wb + pl.dY,
                          last ? pl.pool_n : 0, last ? 1.0f / (float)pl.pool_n : 1.0f, wf + pl.agg[l], params[pg_layer(l, 3)], wb + pl.dagg, rows,
@@ -1388,9 +1391,8 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
     if (fast) {
       GAT_STREAM_FAST(gat_bwd_att_fast_kernel, wf + pl.Z[l], wb + pl.dZ, wb + pl.das, wb + pl.dad, params[pg_layer(l, 1)],
                       params[pg_layer(l, 2)], slot_s, slot_d);
-      hipLaunchKernelGGL(fold_slots_kernel, dim3(ceil_div(D, 64)), dim3(64), 0, st, slot_s, grads[pg_layer(l, 1)], D);
-      OCEAN_LAUNCH_CHECK();
-      hipLaunchKernelGGL(fold_slots_kernel, dim3(ceil_div(D, 64)), dim3(64), 0, st, slot_d, grads[pg_layer(l, 2)], D);
+      const FoldBatch fb{{{slot_b, grads[pg_layer(l, 3)], od}, {slot_s, grads[pg_layer(l, 1)], D}, {slot_d, grads[pg_layer(l, 2)], D}}};
+      hipLaunchKernelGGL(fold_slots_kernel, dim3(ceil_div(D, 64), 3), dim3(64), 0, st, fb);
       OCEAN_LAUNCH_CHECK();
     } else {
       hipLaunchKernelGGL(gat_bwd_att_param_kernel, dim3(ceil_div(D, 64), ceil_div(rows, kAttRows)), dim3(64), 0, st, wf + pl.Z[l],
