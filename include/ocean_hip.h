@@ -222,18 +222,22 @@ int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const f
 /* The three in-batch pairs of ContrastiveLearningModule.forward in one call (graph_fusion.py:231-249 builds the pairs
  * (temporal, spatial), (temporal, log), (spatial, log) and calls InfoNCELoss.forward, :112-162, on each).
  * Z [3, B, P] holds the three projections; losses[q] is ACCUMULATED (+= mean over B rows) for pair q in that order.
- * Same values as three ocean_infonce_fwd calls with K == 0, Bp == B; single-process in-batch negatives only.
+ * Bp == 0: the positives are Z's own rows (one process); same values as three ocean_infonce_fwd calls with K == 0.
+ * Bp > 0 (data parallel): G [3, Bp, P] holds the projections gathered from every rank; local row r is matched with
+ * gathered row label_offset + r; the backward call then also returns dG [3, Bp, P] (for the gather's reduce-scatter).
  * The forward workspace carries the state the backward call needs (it is modified by it). */
 typedef struct {
   int B, P;
   float tau;
+  int Bp, label_offset;
 } ocean_infonce3_shape;
 size_t ocean_infonce3_workspace(const ocean_infonce3_shape* s);
 size_t ocean_infonce3_bwd_workspace(const ocean_infonce3_shape* s);
-int ocean_infonce3_fwd(const ocean_infonce3_shape* s, const float* Z, float* ws, size_t ws_floats, float* losses /* [3] */,
-                       void* stream);
+int ocean_infonce3_fwd(const ocean_infonce3_shape* s, const float* Z, const float* G /* NULL iff Bp == 0 */, float* ws,
+                       size_t ws_floats, float* losses /* [3] */, void* stream);
 int ocean_infonce3_bwd(const ocean_infonce3_shape* s, float* ws, float* ws_bwd, size_t ws_bwd_floats,
-                       const float* dlosses /* device [3] or NULL (= 1, 1, 1) */, float* dZ /* [3, B, P] */, void* stream);
+                       const float* dlosses /* device [3] or NULL (= 1, 1, 1) */, float* dZ /* [3, B, P] */,
+                       float* dG /* [3, Bp, P]; NULL iff Bp == 0 */, void* stream);
 
 /* MINE estimates of GraphFusionModule._compute_mutual_information (graph_fusion.py:475-501) for the three modalities:
  * mi[m] = mean_b f(cat(fused_b, X_{b,m})) - log(mean_b exp f(cat(fused_b, X_{perms[m][b],m})) + 1e-8),

@@ -271,17 +271,22 @@ int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const f
 
 // ---------------------------------------------------------------- the three in-batch pairs at once
 // Z [3, B, P]: the three modality projections.  Pair q of {(0,1), (0,2), (1,2)} takes rows of Z[a] as anchors and rows
-// of Z[b] as positives.  Every projection is re-normalised once (InfoNCELoss does it per call, with the same result),
-// the three similarity matrices come from one batched GEMM launch, and one row kernel finishes all three losses.
+// of the positives' [b] as positives; the positives are Z itself, or (data parallel) G [3, Bp, P] = Z gathered from
+// every rank, in which local row r is matched with gathered row label_offset + r.  Every projection is re-normalised
+// once (InfoNCELoss does it per call, with the same result), the three similarity matrices come from one batched GEMM
+// launch, and one row kernel finishes all three losses.
 namespace {
-struct Nce3Plan { size_t zh, nrm, sim, lse, total; };
+struct Nce3Plan { int Bp; size_t zh, nrm, gh, gnrm, sim, lse, total; };
 int nce3_plan(const ocean_infonce3_shape* s, Nce3Plan* p) {
   if (!s) return OCEAN_ERR_NULL;
-  if (s->B <= 0 || s->P <= 0 || !(s->tau > 0.f)) return OCEAN_ERR_BAD_SHAPE;
+  if (s->B <= 0 || s->P <= 0 || !(s->tau > 0.f) || s->Bp < 0 || s->label_offset < 0) return OCEAN_ERR_BAD_SHAPE;
+  p->Bp = s->Bp > 0 ? s->Bp : s->B;
+  if (s->label_offset + s->B > p->Bp) return OCEAN_ERR_BAD_SHAPE;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o = al4(o + n); return r; };
   p->zh = take((size_t)3 * s->B * s->P); p->nrm = take((size_t)3 * s->B);
-  p->sim = take((size_t)3 * s->B * s->B); p->lse = take((size_t)3 * s->B);
+  p->gh = take(s->Bp > 0 ? (size_t)3 * p->Bp * s->P : 0); p->gnrm = take(s->Bp > 0 ? (size_t)3 * p->Bp : 0);
+  p->sim = take((size_t)3 * s->B * p->Bp); p->lse = take((size_t)3 * s->B);
   p->total = o;
   return OCEAN_OK;
 }
@@ -289,64 +294,78 @@ constexpr int kPairA[3] = {0, 0, 1}, kPairB[3] = {1, 2, 2};
 }  // namespace
 
 size_t ocean_infonce3_workspace(const ocean_infonce3_shape* s) { Nce3Plan p; return nce3_plan(s, &p) == OCEAN_OK ? p.total : 0; }
-size_t ocean_infonce3_bwd_workspace(const ocean_infonce3_shape* s) { return s ? al4((size_t)3 * s->B * s->P) : 0; }
+size_t ocean_infonce3_bwd_workspace(const ocean_infonce3_shape* s) {
+  return s ? (size_t)3 * s->B * s->P + (s->Bp > 0 ? (size_t)3 * s->Bp * s->P : 0) + 4 : 0;
+}
 
-int ocean_infonce3_fwd(const ocean_infonce3_shape* s, const float* Z, float* ws, size_t ws_floats, float* losses, void* stream) {
+int ocean_infonce3_fwd(const ocean_infonce3_shape* s, const float* Z, const float* G, float* ws, size_t ws_floats, float* losses,
+                       void* stream) {
   Nce3Plan pl;
   OCEAN_TRY(nce3_plan(s, &pl));
-  if (!Z || !ws || !losses) return OCEAN_ERR_NULL;
+  if (!Z || !ws || !losses || (s->Bp > 0 && !G)) return OCEAN_ERR_NULL;
   if (ws_floats < pl.total) return OCEAN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const int B = s->B, P = s->P;
-  const size_t BP = (size_t)B * P, BB = (size_t)B * B;
+  const int B = s->B, P = s->P, Bp = pl.Bp;
+  const size_t BP = (size_t)B * P, GP = (size_t)Bp * P, BB = (size_t)B * Bp;
   OCEAN_TRY(l2norm_fwd(Z, P, ws + pl.zh, P, ws + pl.nrm, 3 * B, P, 1e-12f, st));
+  const float* pos = ws + pl.zh;
+  if (s->Bp > 0) {
+    OCEAN_TRY(l2norm_fwd(G, P, ws + pl.gh, P, ws + pl.gnrm, 3 * Bp, P, 1e-12f, st));
+    pos = ws + pl.gh;
+  }
   GemmP g[3];
   for (int q = 0; q < 3; ++q) {
     g[q] = gemm_defaults();
-    g[q].A = ws + pl.zh + kPairA[q] * BP; g[q].lda = P; g[q].B = ws + pl.zh + kPairB[q] * BP; g[q].ldb = P;
-    g[q].C = ws + pl.sim + q * BB; g[q].ldc = B; g[q].M = B; g[q].N = B; g[q].K = P;
+    g[q].A = ws + pl.zh + kPairA[q] * BP; g[q].lda = P; g[q].B = pos + kPairB[q] * GP; g[q].ldb = P;
+    g[q].C = ws + pl.sim + q * BB; g[q].ldc = Bp; g[q].M = B; g[q].N = Bp; g[q].K = P;
   }
   OCEAN_TRY(ocean_launch_gemm_batch(g, 3, st));
-  hipLaunchKernelGGL(nce_rows_fwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, ws + pl.sim, B, 3 * B, B, 0, 1, 1.0f / s->tau,
-                     1.0f / (float)B, ws + pl.lse, losses, B);
+  hipLaunchKernelGGL(nce_rows_fwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, ws + pl.sim, Bp, 3 * B, Bp, s->label_offset, 1,
+                     1.0f / s->tau, 1.0f / (float)B, ws + pl.lse, losses, B);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }
 
 int ocean_infonce3_bwd(const ocean_infonce3_shape* s, float* ws, float* wb, size_t wb_floats, const float* dlosses, float* dZ,
-                       void* stream) {
+                       float* dG, void* stream) {
   Nce3Plan pl;
   OCEAN_TRY(nce3_plan(s, &pl));
-  if (!ws || !wb || !dZ) return OCEAN_ERR_NULL;
+  if (!ws || !wb || !dZ || (s->Bp > 0 && !dG)) return OCEAN_ERR_NULL;
   if (wb_floats < ocean_infonce3_bwd_workspace(s)) return OCEAN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const int B = s->B, P = s->P;
-  const size_t BP = (size_t)B * P, BB = (size_t)B * B;
-  float* sim = ws + pl.sim; float* zh = ws + pl.zh; float* dzh = wb;
-  hipLaunchKernelGGL(nce_rows_bwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, sim, B, 3 * B, B, 0, 1, 1.0f / s->tau, 1.0f / (float)B,
-                     ws + pl.lse, dlosses, B);
+  const int B = s->B, P = s->P, Bp = pl.Bp;
+  const bool gathered = s->Bp > 0;
+  const size_t BP = (size_t)B * P, GP = (size_t)Bp * P, BB = (size_t)B * Bp;
+  float* sim = ws + pl.sim; float* zh = ws + pl.zh;
+  const float* pos = gathered ? ws + pl.gh : zh;
+  float* dzh = wb;                                  // [3, B, P]
+  float* dph = gathered ? wb + 3 * BP : dzh;        // gradient of the normalised positives: its own [3, Bp, P], or the anchors' buffer
+  hipLaunchKernelGGL(nce_rows_bwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, sim, Bp, 3 * B, Bp, s->label_offset, 1, 1.0f / s->tau,
+                     1.0f / (float)B, ws + pl.lse, dlosses, B);
   OCEAN_LAUNCH_CHECK();
-  // anchors: d zh[a] (+)= G_q . zh[b]   (G_q = the rewritten similarity matrix of pair q)
+  // anchors: d zh[a] (+)= G_q . pos[b]   (G_q = the rewritten similarity matrix of pair q)
   GemmP g[3];
   for (int q = 0; q < 3; ++q) {
     g[q] = gemm_defaults();
-    g[q].A = sim + q * BB; g[q].lda = B; g[q].B = zh + kPairB[q] * BP; g[q].ldb = P; g[q].b_kn = 1;
-    g[q].C = dzh + kPairA[q] * BP; g[q].ldc = P; g[q].M = B; g[q].N = P; g[q].K = B;
+    g[q].A = sim + q * BB; g[q].lda = Bp; g[q].B = pos + kPairB[q] * GP; g[q].ldb = P; g[q].b_kn = 1;
+    g[q].C = dzh + kPairA[q] * BP; g[q].ldc = P; g[q].M = B; g[q].N = P; g[q].K = Bp;
   }
   GemmP first[2] = {g[0], g[2]};                       // pairs (0,1) and (1,2) write d zh[0] and d zh[1]
   OCEAN_TRY(ocean_launch_gemm_batch(first, 2, st));
   g[1].R = g[1].C; g[1].ldr = P;                       // pair (0,2) adds to d zh[0]
   OCEAN_TRY(ocean_launch_gemm(g[1], st));
-  // positives: d zh[b] += G_q^T . zh[a]  (row reductions: they accumulate with atomics, so two may share an output)
-  OCEAN_TRY(zero_f32(dzh + 2 * BP, BP, st));
+  // positives: d pos[b] += G_q^T . zh[a]  (row reductions: they accumulate with atomics, so two may share an output).
+  // d zh[2] has no anchor term; with gathered positives none of d pos has been written yet: one fill covers both.
+  OCEAN_TRY(zero_f32(dzh + 2 * BP, BP + (gathered ? 3 * GP : 0), st));
   GemmP t[3];
   for (int q = 0; q < 3; ++q) {
     t[q] = gemm_defaults();
-    t[q].A = sim + q * BB; t[q].lda = B; t[q].a_kmajor = 1; t[q].B = zh + kPairA[q] * BP; t[q].ldb = P; t[q].b_kn = 1;
-    t[q].C = dzh + kPairB[q] * BP; t[q].ldc = P; t[q].M = B; t[q].N = P; t[q].K = B; t[q].split_k = 0;
+    t[q].A = sim + q * BB; t[q].lda = Bp; t[q].a_kmajor = 1; t[q].B = zh + kPairA[q] * BP; t[q].ldb = P; t[q].b_kn = 1;
+    t[q].C = dph + kPairB[q] * GP; t[q].ldc = P; t[q].M = Bp; t[q].N = P; t[q].K = B; t[q].split_k = 0;
   }
   OCEAN_TRY(ocean_launch_gemm_batch(t, 3, st));
   OCEAN_TRY(l2norm_bwd(dzh, P, zh, P, ws + pl.nrm, dZ, P, 3 * B, P, 1e-12f, st));
+  if (gathered) OCEAN_TRY(l2norm_bwd(dph, P, ws + pl.gh, P, ws + pl.gnrm, dG, P, 3 * Bp, P, 1e-12f, st));
   return OCEAN_OK;
 }
 

@@ -80,7 +80,7 @@ class InfoNceShape(ctypes.Structure):
 
 
 class InfoNce3Shape(ctypes.Structure):
-    _fields_ = [("B", c_int), ("P", c_int), ("tau", c_float)]
+    _fields_ = [("B", c_int), ("P", c_int), ("tau", c_float), ("Bp", c_int), ("label_offset", c_int)]
 
 
 class MiShape(ctypes.Structure):
@@ -120,8 +120,8 @@ def _declare_rest(lib) -> None:
     i3 = ctypes.POINTER(InfoNce3Shape)
     sig("ocean_infonce3_workspace", c_size_t, i3)
     sig("ocean_infonce3_bwd_workspace", c_size_t, i3)
-    sig("ocean_infonce3_fwd", c_int, i3, vp, vp, c_size_t, vp, vp)
-    sig("ocean_infonce3_bwd", c_int, i3, vp, vp, c_size_t, vp, vp, vp)
+    sig("ocean_infonce3_fwd", c_int, i3, vp, vp, vp, c_size_t, vp, vp)
+    sig("ocean_infonce3_bwd", c_int, i3, vp, vp, c_size_t, vp, vp, vp, vp)
     mp = ctypes.POINTER(MiShape)
     sig("ocean_mi_workspace", c_size_t, mp)
     sig("ocean_mi_estimates", c_int, mp, vp, vp, vp, vp, vp, vp, vp, vp, c_size_t, vp, vp)

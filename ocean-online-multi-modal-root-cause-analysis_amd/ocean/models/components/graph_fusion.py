@@ -93,9 +93,14 @@ class ContrastiveLearningModule(nn.Module):
         names = list(projections.keys())
         losses = {}
         neg = self._get_negatives() if self.negatives == "bank" else None
-        if (neg is None and self.gather_positives is None and stacked is not None and len(names) == 3 and stacked.shape[0] == 3
-                and self.batch_pairs):
-            three = ops.infonce_pairs(stacked, self.infonce_loss.temperature).unbind(0)   # one backward node for the three scalars
+        if neg is None and stacked is not None and len(names) == 3 and stacked.shape[0] == 3 and self.batch_pairs:
+            gathered, offset = None, 0
+            if self.gather_positives is not None:
+                # data parallel: one collective over the three projections side by side (its backward: one reduce-scatter)
+                B, P = stacked.shape[1], stacked.shape[2]
+                allz = self.gather_positives(stacked.permute(1, 0, 2).reshape(B, 3 * P))          # [B_all, 3P]
+                gathered, offset = allz.view(-1, 3, P).permute(1, 0, 2), self.rank_row_offset(B)
+            three = ops.infonce_pairs(stacked, self.infonce_loss.temperature, gathered, offset).unbind(0)   # one backward node
             pairs = [(a, b) for i, a in enumerate(names) for b in names[i + 1:]]
             return {f"{a}_{b}_contrastive": three[q] for q, (a, b) in enumerate(pairs)}
         gathered = {}

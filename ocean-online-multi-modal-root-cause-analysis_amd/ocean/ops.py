@@ -62,18 +62,22 @@ def infonce(anchor: torch.Tensor, positive: torch.Tensor, negatives: Optional[to
 
 class _InfoNce3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, Z, tau):
+    def forward(ctx, Z, G, tau, label_offset):
         L = _hip.lib()
         sh = _hip.InfoNce3Shape()
         _, sh.B, sh.P = Z.shape
         sh.tau = tau
+        sh.Bp = 0 if G is None else G.shape[1]
+        sh.label_offset = label_offset
         ws = torch.empty(L.ocean_infonce3_workspace(ctypes.byref(sh)), device=Z.device, dtype=torch.float32)
+        if ws.numel() == 0:
+            raise ValueError("infonce_pairs: label_offset + local rows must fit the gathered rows")
         losses = torch.zeros(3, device=Z.device, dtype=torch.float32)
-        _hip.check(L.ocean_infonce3_fwd(ctypes.byref(sh), _hip.dev_ptr(Z, "projections"), _hip.dev_ptr(ws), ws.numel(),
-                                        _hip.dev_ptr(losses), _hip.stream()), "ocean_infonce3_fwd")
+        _hip.check(L.ocean_infonce3_fwd(ctypes.byref(sh), _hip.dev_ptr(Z, "projections"), _hip.dev_ptr(G, "gathered projections"),
+                                        _hip.dev_ptr(ws), ws.numel(), _hip.dev_ptr(losses), _hip.stream()), "ocean_infonce3_fwd")
         ctx.sh = sh
         ctx.save_for_backward(ws)
-        ctx.shape = Z.shape
+        ctx.shapes = (Z.shape, None if G is None else G.shape)
         return losses
 
     @staticmethod
@@ -82,20 +86,28 @@ class _InfoNce3(torch.autograd.Function):
         (ws,) = ctx.saved_tensors
         sh = ctx.sh
         wb = torch.empty(L.ocean_infonce3_bwd_workspace(ctypes.byref(sh)), device=ws.device, dtype=torch.float32)
-        dZ = torch.empty(ctx.shape, device=ws.device, dtype=torch.float32)
+        dZ = torch.empty(ctx.shapes[0], device=ws.device, dtype=torch.float32)
+        dG = None if ctx.shapes[1] is None else torch.empty(ctx.shapes[1], device=ws.device, dtype=torch.float32)
         _hip.check(L.ocean_infonce3_bwd(ctypes.byref(sh), _hip.dev_ptr(ws), _hip.dev_ptr(wb), wb.numel(),
-                                        _hip.dev_ptr(dlosses.contiguous().float(), "dlosses"), _hip.dev_ptr(dZ), _hip.stream()),
-                   "ocean_infonce3_bwd")
-        return dZ, None
+                                        _hip.dev_ptr(dlosses.contiguous().float(), "dlosses"), _hip.dev_ptr(dZ), _hip.dev_ptr(dG),
+                                        _hip.stream()), "ocean_infonce3_bwd")
+        return dZ, dG, None, None
 
 
-def infonce_pairs(projections: torch.Tensor, temperature: float = 0.1) -> torch.Tensor:
+def infonce_pairs(projections: torch.Tensor, temperature: float = 0.1, gathered: Optional[torch.Tensor] = None,
+                  label_offset: int = 0) -> torch.Tensor:
     """The in-batch InfoNCE losses of the pairs (0,1), (0,2), (1,2) of `projections` [3, B, P] as one [3] tensor: what
     three InfoNCELoss.forward(anchor, positive) calls return (graph_fusion.py:112-162, 231-249), from one normalisation,
-    one batched similarity launch and one row pass.  The backward pass consumes the saved state: differentiate once."""
+    one batched similarity launch and one row pass.  `gathered` [3, B_all, P] (data parallel): the projections of every
+    rank, whose rows serve as positives; local row r then pairs with gathered row label_offset + r.  The backward pass
+    consumes the saved state: differentiate once."""
     if projections.dim() != 3 or projections.shape[0] != 3:
         raise ValueError("projections must be [3, B, dim]")
-    return _InfoNce3.apply(projections.contiguous().float(), float(temperature))
+    if gathered is not None:
+        if gathered.dim() != 3 or gathered.shape[0] != 3 or gathered.shape[2] != projections.shape[2]:
+            raise ValueError("gathered must be [3, B_all, dim]")
+        gathered = gathered.contiguous().float()
+    return _InfoNce3.apply(projections.contiguous().float(), gathered, float(temperature), int(label_offset))
 
 
 class _Bce(torch.autograd.Function):

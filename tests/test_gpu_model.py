@@ -323,3 +323,37 @@ def test_three_pair_infonce_equals_three_single_calls_and_the_oracle(B, P):
     (single * w.cuda()).sum().backward()
     close(got, single, 1e-6)
     close(zg.grad, zs.grad, 1e-4)
+
+
+def test_three_pair_infonce_with_gathered_positives_equals_per_pair_calls():
+    """Data-parallel form: anchors are this rank's rows, positives the rows gathered from every rank, labels offset by
+    the rank's row base (InfoNCELoss's in-batch branch, graph_fusion.py:144-157, over local rows x global columns)."""
+    from ocean import ops
+    B, Ball, P, off = 6, 17, 24, 8
+    g = torch.Generator().manual_seed(3)
+    G = torch.randn(3, Ball, P, generator=g)
+    Z = G[:, off:off + B].clone()
+    w = torch.tensor([0.7, -1.1, 2.0])
+    pairs = ((0, 1), (0, 2), (1, 2))
+
+    def oracle_loss(a, allb):                     # cross entropy of a . allb^T / tau against labels off + r
+        a, allb = torch.nn.functional.normalize(a, dim=1), torch.nn.functional.normalize(allb, dim=1)
+        return torch.nn.functional.cross_entropy(a @ allb.t() / 0.1, torch.arange(B) + off)
+
+    zr, gr = Z.clone().requires_grad_(True), G.clone().requires_grad_(True)
+    ref = torch.stack([oracle_loss(zr[a], gr[b]) for a, b in pairs])
+    (ref * w).sum().backward()
+    zg, gg = Z.clone().cuda().requires_grad_(True), G.clone().cuda().requires_grad_(True)
+    got = ops.infonce_pairs(zg, 0.1, gathered=gg, label_offset=off)
+    (got * w.cuda()).sum().backward()
+    close(got, ref, 1e-5)
+    close(zg.grad, zr.grad, 1e-3)
+    close(gg.grad, gr.grad, 1e-3)
+    zs, gs = Z.clone().cuda().requires_grad_(True), G.clone().cuda().requires_grad_(True)
+    single = torch.stack([ops.infonce(zs[a], gs[b], None, 0.1, label_offset=off) for a, b in pairs])
+    (single * w.cuda()).sum().backward()
+    close(got, single, 1e-6)
+    close(zg.grad, zs.grad, 1e-4)
+    close(gg.grad, gs.grad, 1e-4)
+    with pytest.raises(ValueError):
+        ops.infonce_pairs(zg, 0.1, gathered=gg, label_offset=Ball)      # rows would fall outside the gathered set
