@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copies the summaries under gpurun_out/final/ (written by collect_profiles.sh and collect_micro.sh on the GPU box)
-# into profiles/ under this round's prefix.  usage: tools/publish_profiles.sh r01
+# into profiles/ under the given file-name prefix.  usage: tools/publish_profiles.sh r01
 set -e
 P=${1:-r01}
 F=gpurun_out/final
