@@ -141,10 +141,15 @@ def main():
                 _bc(c, src=src, group=group)
                 t.detach().copy_(c)
 
-            def _all_reduce(t, op=dist.ReduceOp.SUM, group=None):
+            class _Done:
+                def wait(self):
+                    return True
+
+            def _all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
                 c = t.detach().cpu()
                 _ar(c, op=op, group=group)
                 t.detach().copy_(c)
+                return _Done() if async_op else None
 
             def _all_gather_into_tensor(out, x, group=None):
                 c = torch.empty(out.shape, dtype=out.dtype)

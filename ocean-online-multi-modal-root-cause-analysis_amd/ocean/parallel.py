@@ -15,6 +15,7 @@ collective on torch.distributed's default backend ("nccl" == RCCL on ROCm,
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -58,6 +59,31 @@ class GradBucket:
         self.group = group
         self._flat: Optional[torch.Tensor] = None
 
+    def start(self, grads: List[torch.Tensor]):
+        """Pack and launch the all-reduce without waiting for it; finish() averages and unpacks.  The collective runs
+        on the backend's own stream, ordered after the packing copies, so kernels queued afterwards overlap it."""
+        self._views = self._pack(grads)
+        self._grads = grads
+        self._work = dist.all_reduce(self._flat, group=self.group, async_op=True) if grads else None
+
+    def finish(self) -> None:
+        if getattr(self, "_work", None) is not None:
+            self._work.wait()                     # the current stream waits for the collective
+            self._flat.div_(dist.get_world_size(self.group))
+            torch._foreach_copy_(self._grads, self._views)
+        self._work = self._grads = self._views = None
+
+    def _pack(self, grads: List[torch.Tensor]) -> List[torch.Tensor]:
+        n = sum(g.numel() for g in grads)
+        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
+            self._flat = torch.empty(n, device=grads[0].device, dtype=torch.float32)
+        views, off = [], 0
+        for g in grads:
+            views.append(self._flat[off: off + g.numel()].view_as(g))
+            off += g.numel()
+        torch._foreach_copy_(views, grads)
+        return views
+
     def all_reduce_mean(self, grads: List[torch.Tensor]) -> None:
         if not grads:
             return
@@ -83,7 +109,7 @@ class DataParallel:
     CNN all-reduces its BatchNorm statistics (sync_bn) and the contrastive
     module gathers in-batch negatives from every rank."""
 
-    def __init__(self, model, learner=None, group=None, sync_bn: bool = True):
+    def __init__(self, model, learner=None, group=None, sync_bn: bool = True, early_bucket: Optional[bool] = None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.model, self.group = model, group
@@ -92,6 +118,19 @@ class DataParallel:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t, src=0, group=group)
         self.bucket = GradBucket(group)
+        # early_bucket (opt-in; OCEAN_DP_EARLY_BUCKET=1): gradients of the attention / fusion / head stages are complete
+        # when backward reaches the temporal encoder, whose backward is most of the step; their all-reduce is started
+        # there and runs under it, the encoders' gradients follow at the end.  Off by default: with one rank it costs
+        # 0.15 ms of host time per step, and what it hides on N ranks has not been measured.
+        self.early_bucket = GradBucket(group)
+        self._early_ids = set()
+        self._early_started = False
+        if early_bucket is None:
+            early_bucket = os.environ.get("OCEAN_DP_EARLY_BUCKET") == "1"
+        if learner is not None and early_bucket:
+            late = {id(p) for enc in (model.temporal_encoder, model.spatial_encoder) for p in enc.parameters()}
+            self._early_ids = {id(p) for p in model.parameters() if id(p) not in late}
+            model.temporal_encoder.register_forward_hook(self._watch_encoder_output)
         if sync_bn:
             enc = model.temporal_encoder
             enc.stats_all_reduce = lambda t: dist.all_reduce(t, group=group)
@@ -102,9 +141,29 @@ class DataParallel:
         if learner is not None:
             learner.grad_sync = self.sync_grads
 
+    def _watch_encoder_output(self, module, inputs, output):
+        if torch.is_tensor(output) and output.requires_grad and torch.is_grad_enabled():
+            output.register_hook(self._start_early_bucket)
+
+    def _start_early_bucket(self, grad):
+        """Runs inside backward, when the gradient of the temporal encoder's output is known: every stage after the
+        encoders has finished its backward (parameter gradients are accumulated before the engine moves on)."""
+        if not self._early_started:
+            grads = [p.grad for p in self.model.parameters() if id(p) in self._early_ids and p.grad is not None]
+            if grads:
+                self.early_bucket.start(grads)
+                self._early_started = True
+                self._early_set = {id(g) for g in grads}
+        return None
+
     def sync_grads(self, model=None) -> None:
         model = model or self.model
         # every rank must contribute the same tensors: parameters without a gradient on this rank
         # (none on the OCEAN path) would desynchronise the bucket, so the set is taken by name order
         grads = [p.grad for p in model.parameters() if p.grad is not None]
-        self.bucket.all_reduce_mean(grads)
+        if self._early_started:
+            self.bucket.all_reduce_mean([g for g in grads if id(g) not in self._early_set])
+            self.early_bucket.finish()
+            self._early_started = False
+        else:
+            self.bucket.all_reduce_mean(grads)

@@ -199,3 +199,78 @@ def test_two_ranks_reproduce_single_process_full_batch():
         for r in (0, 1):
             close(out[r]["grads"][k], gref, 1e-3)              # averaged gradients == full-batch gradients, on both ranks
     close(out[0]["rm"], rsd["temporal_encoder.conv_layers.1.batch_norm.running_mean"], 1e-5)
+
+
+def _dp_class_worker(rank, world, port, fix, out):
+    import faulthandler
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(90, exit=True)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        import ocean
+        from ocean.data import ServiceGraph
+        from ocean.models.training import OnlineLearner
+        from ocean.parallel import DataParallel
+        cfg = tiny_config()
+        m = ocean.OCEANModel(cfg)
+        zero_dropout(m)
+        m.load_state_dict({k: v.clone() for k, v in fix["sd"].items()})
+        m = m.cuda()
+        m.contrastive_negatives = "in_batch"
+        learner = OnlineLearner(m, cfg)
+        dp = DataParallel(m, learner, early_bucket=True)
+        sg = ServiceGraph(fix["adj"], fix["nf"])
+        m.train()
+        res = {}
+        for step in range(2):                      # the second pass reuses the buckets
+            o = m(fix["metrics"], sg, fix["logs"])
+            losses = m.compute_loss(o, fix["labels"].cuda())
+            learner.optimizer.zero_grad()
+            losses["total_loss"].backward()
+            started = dp._early_started
+            n_early = len(dp._early_set) if started else 0
+            before = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+            learner.grad_sync(m)
+            torch.cuda.synchronize()
+            same = all(torch.equal(before[k], p.grad) for k, p in m.named_parameters() if p.grad is not None)
+            res[step] = {"started": bool(started), "n_early": n_early, "n_all": len(before), "same": bool(same),
+                         "reset": not dp._early_started}
+        res["grads"] = {k: v.cpu() for k, v in before.items()}
+        res["loss"] = float(losses["total_loss"].detach())
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_class_on_one_rccl_rank_leaves_gradients_exact():
+    """ocean.parallel.DataParallel itself (RCCL backend, one rank) with early_bucket=True: the gradient all-reduce is split into a bucket
+    started from inside backward, when the temporal encoder's output gradient arrives, and a bucket for the encoders
+    afterwards.  With one rank the average is the identity, so every gradient must come back bit-identical - which it
+    would not if the early bucket were packed before some gradient it covers was complete - and the model's gradients
+    must be those of the single-process oracle."""
+    import torch.multiprocessing as mp
+    import ocean
+    cfg = tiny_config()
+    sd = synth.fill_state_dict(ocean.OCEANModel(cfg).state_dict(), 21)
+    g = torch.Generator().manual_seed(5)
+    B = 8
+    fix = {"sd": sd, "metrics": torch.randn(B, 12, 5, generator=g), "logs": torch.randn(B, 24, generator=g),
+           "adj": synth.random_digraph(6, 2.0, 2), "nf": torch.randn(6, 7, generator=g), "labels": torch.zeros(B, 6)}
+    fix["labels"][torch.arange(B), torch.randint(0, 6, (B,), generator=g)] = 1
+    rsd = R.require_grad(sd)
+    ro = R.model_forward(rsd, fix["metrics"], fix["adj"], fix["nf"], fix["logs"], training=True, negatives="in_batch",
+                         dilations=(1, 2), gnn_heads=2, log_dim=24)
+    rl = R.compute_loss(ro, fix["labels"])
+    rl["total_loss"].backward()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_dp_class_worker, args=(1, _free_port(), fix, out), nprocs=1, join=True)
+    r = out[0]
+    for step in (0, 1):
+        assert r[step]["started"] and r[step]["same"] and r[step]["reset"], r[step]
+        assert 0 < r[step]["n_early"] < r[step]["n_all"], r[step]
+    assert abs(r["loss"] - float(rl["total_loss"])) < 1e-3 * abs(float(rl["total_loss"]))
+    for k, gref in ((k, v.grad) for k, v in rsd.items() if v.grad is not None):
+        close(r["grads"][k], gref, 1e-3)
