@@ -317,6 +317,12 @@ int ocean_clip_adam_step_dev(const ocean_adam_chunk* table, int n_chunks, const 
 int ocean_prof_enable(int on);
 int ocean_prof_summary(char* buf, size_t cap);
 
+/* Every entry point reports a failed launch by reading the runtime's last-error slot, which also holds errors left by
+ * the caller's own HIP calls (a stream capture that was invalidated, for one).  A caller that has handled such an error
+ * calls this before its next library call; returns the cleared HIP error code (0: none).  No counterpart in the
+ * reference. */
+int ocean_clear_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,8 @@ void ocean_prof_end(void* token, hipStream_t s) {
 
 extern "C" {
 
+int ocean_clear_last_error(void) { return (int)hipGetLastError(); }
+
 int ocean_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

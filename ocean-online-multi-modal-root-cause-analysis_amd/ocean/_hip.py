@@ -139,6 +139,7 @@ def _declare_rest(lib) -> None:
     sig("ocean_diversity_fwd", c_int, vp, c_int, c_int, vp, c_size_t, vp, vp)
     sig("ocean_diversity_bwd", c_int, c_int, c_int, vp, vp, vp, vp)
     sig("ocean_prof_enable", c_int, c_int)
+    sig("ocean_clear_last_error", c_int)
     sig("ocean_prof_summary", c_int, ctypes.c_char_p, c_size_t)
     sig("ocean_grad_sqnorm", c_int, vp, c_int, vp, vp)
     sig("ocean_clip_adam_step", c_int, vp, c_int, vp, c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_int, vp)
@@ -251,6 +252,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
                               ldr or ldc, int(relu), stream())
     check(st, "ocean_gemm_f32")
     return out
+
+
+def clear_last_error() -> int:
+    """Drop an error the HIP runtime still holds from a failed operation of the caller (e.g. an invalidated stream
+    capture), so that the next library call does not report it as its own."""
+    return int(lib().ocean_clear_last_error())
 
 
 def profile_enable(on: bool) -> None:

@@ -205,6 +205,7 @@ class OnlineLearner:
         # use_hip_graph: after two eager steps with the same batch shape and graph, process_tensors records the
         # step as a HIP graph and replays it from then on (single-GPU, FusedAdam, in-batch contrastive mode)
         self.use_hip_graph = False
+        self.max_graphs = 4            # recorded steps kept (each owns its activations' memory); least recently used goes first
         self._graphed: Dict[Any, _GraphedStep] = {}
         # pinned_staging: process_batch collates host samples through page-locked buffers and reused device
         # tensors (ocean/staging.py) instead of three pageable torch.stack results; same values either way
@@ -350,14 +351,26 @@ class OnlineLearner:
             self._graph_seen[key] += 1
             if self._graph_seen[key] <= 2:
                 return None
+            before = torch.cuda.current_stream(self.model.device)
             try:
                 step = _GraphedStep(self, metrics, service_graph, logs, labels)
-            except Exception as e:      # keep training eagerly if this step cannot be recorded
-                logger.warning("HIP graph capture failed (%s); continuing without it", e)
+            except Exception as e:
+                # The configurations known not to be capturable were turned away above, so this is a defect, and not
+                # one to train through: a recording that dies half-way leaves PyTorch's capture bookkeeping (current
+                # stream, random generator, allocator pool) in a state eager launches cannot rely on.  Put back what can
+                # be put back, switch recording off for this learner, and say so.
+                torch.cuda.set_stream(before)
+                _hip.clear_last_error()
                 self.use_hip_graph = False
                 self.optimizer.zero_grad(set_to_none=True)
-                return None
+                raise RuntimeError("recording the update step as a HIP graph failed; use_hip_graph has been switched off for "
+                                   "this learner, but the process should be restarted before training on") from e
+            while len(self._graphed) >= max(1, self.max_graphs):
+                old = self._graphed.pop(next(iter(self._graphed)))      # dicts keep insertion order; a hit re-inserts (below)
+                self.optimizer.recycle_table_host(old._keep[0])
             self._graphed[key] = step
+        else:
+            self._graphed[key] = self._graphed.pop(key)           # mark as most recently used
         return step.replay(self, metrics, logs, labels)
 
     def _remember(self, sample: DatasetSample, importance_score: float) -> None:

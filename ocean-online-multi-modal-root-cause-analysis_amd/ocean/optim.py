@@ -17,6 +17,12 @@ import torch
 
 from . import _hip
 
+# Page-locked table buffers that took part in a stream capture are never handed back to PyTorch's host allocator: the
+# allocator would later query the event it recorded for them on the capturing stream, which HIP refuses
+# (hipErrorCapturedEvent) and which invalidates whatever capture is running at that moment.  They are small (40 bytes per
+# 2048 parameters); buffers of dropped recordings are reused by later ones.
+_CAPTURED_PINNED: list = []
+
 _CHUNK = 2048     # elements per block of the update kernels: ~1700 blocks for 3.3 M parameters (330 blocks of 16384 left most CUs idle)
 
 
@@ -33,6 +39,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._step_dev: Optional[torch.Tensor] = None
         self._lr_host: Optional[float] = None
         self._table_host = None
+        self._table_free: list = []          # pinned table buffers of dropped recordings (see _CAPTURED_PINNED)
 
     def _build_table(self, entries, device):
         rows = []
@@ -43,9 +50,26 @@ class FusedAdam(torch.optim.Optimizer):
                 rows.append((p.data_ptr() + 4 * base, g.data_ptr() + 4 * base, m.data_ptr() + 4 * base, v.data_ptr() + 4 * base, c))
                 base += c
         # pinned staging + asynchronous copy: legal inside a stream capture, where it becomes a copy node that
-        # re-reads this host buffer on every replay (so the buffer is kept alive)
-        self._table_host = torch.tensor(rows, dtype=torch.int64).pin_memory()    # 5 x int64 per row == ocean_adam_chunk
-        return self._table_host.to(device, non_blocking=True), len(rows)
+        # re-reads this host buffer on every replay (so the buffer is kept alive and unchanged while the graph lives)
+        table = torch.tensor(rows, dtype=torch.int64)                            # 5 x int64 per row == ocean_adam_chunk
+        host = None
+        for i, buf in enumerate(self._table_free):
+            if buf.shape == table.shape:
+                host = self._table_free.pop(i)
+                break
+        if host is None:
+            host = torch.empty(table.shape, dtype=torch.int64, pin_memory=True)
+            if torch.cuda.is_current_stream_capturing():
+                _CAPTURED_PINNED.append(host)
+        host.copy_(table)
+        self._table_host = host
+        return host.to(device, non_blocking=True), len(rows)
+
+    def recycle_table_host(self, host: Optional[torch.Tensor]) -> None:
+        """Called when a recorded step that used `host` as its table source is dropped: the buffer may serve the next
+        recording.  (The current table's buffer is never recycled while it is current.)"""
+        if host is not None and host is not self._table_host and all(host is not b for b in self._table_free):
+            self._table_free.append(host)
 
     def make_capturable(self, device) -> None:
         """Keep the learning rate and the step count in device memory so that step() can be recorded into a HIP

@@ -120,3 +120,20 @@ def test_bank_mode_and_new_shapes_fall_back_to_eager():
     for i in range(4):
         learner.process_tensors(*(lambda d: (d[0], sg, d[1], d[2]))(_data(i, B=3 + i)))   # a new batch size every step
     assert len(learner._graphed) == 0 and learner.update_count == 4
+
+
+def test_recorded_steps_are_bounded_least_recently_used_first():
+    sg = _graph()
+    m, learner = _learner(True, True)
+    learner.max_graphs = 2
+    data = {B: _data(B, B=B) for B in (2, 3, 4)}
+    for B in (2, 3, 4):
+        for _ in range(4):                       # two eager steps, then recorded, then replayed
+            learner.process_tensors(data[B][0], sg, data[B][1], data[B][2])
+        assert len(learner._graphed) == min(2, B - 1)
+    shapes = [k[0][0] for k in learner._graphed]
+    assert shapes == [3, 4]                      # the batch-2 recording was dropped first
+    learner.process_tensors(data[3][0], sg, data[3][1], data[3][2])      # a hit moves batch 3 to the back
+    assert [k[0][0] for k in learner._graphed] == [4, 3]
+    r = learner.process_tensors(data[2][0], sg, data[2][1], data[2][2])  # seen before: recorded again at once, batch 4 goes
+    assert [k[0][0] for k in learner._graphed] == [3, 2] and r["update_count"] == 14
