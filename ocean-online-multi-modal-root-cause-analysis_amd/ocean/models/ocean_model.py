@@ -259,7 +259,9 @@ class OCEANModel(nn.Module):
     def freeze_component(self, component_name: str):
         for p in self._component(component_name).parameters():
             p.requires_grad = False
+        self.trainable_version = getattr(self, "trainable_version", 0) + 1     # recorded update steps are keyed on it
 
     def unfreeze_component(self, component_name: str):
         for p in self._component(component_name).parameters():
             p.requires_grad = True
+        self.trainable_version = getattr(self, "trainable_version", 0) + 1

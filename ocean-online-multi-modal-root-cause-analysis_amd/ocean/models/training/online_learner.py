@@ -153,6 +153,7 @@ class _GraphedStep:
         self.labels = labels.detach().to(dev, torch.float32).clone()
         self.service_graph = service_graph
         self.epoch = _hip.seed_epoch(dev)
+        self.generation = opt.generation           # recordings made before a load_state_dict point at replaced tensors
         clip = learner.config.training.gradient_clip_norm
         opt.zero_grad(set_to_none=True)            # gradients are re-created inside the graph's memory pool
         torch.cuda.synchronize(dev)
@@ -344,9 +345,16 @@ class OnlineLearner:
                 or self.model.contrastive_negatives != "in_batch"):
             return None
         adj = service_graph.adjacency_matrix
+        # everything a recording bakes in: shapes, the graph's tensors, which components train, and the optimizer's
+        # by-value hyper-parameters (the learning rate and the step count are read from device memory instead)
+        grp = self.optimizer.param_groups[0]
         key = (tuple(metrics.shape), tuple(logs.shape), tuple(labels.shape), id(service_graph), adj._version,
-               service_graph.node_features._version)
+               service_graph.node_features._version, getattr(self.model, "trainable_version", 0),
+               tuple(grp["betas"]), grp["eps"], grp["weight_decay"], self.config.training.gradient_clip_norm)
         step = self._graphed.get(key)
+        if step is not None and step.generation != self.optimizer.generation:
+            self._drop_recordings()                # the optimizer state was reloaded: every recording is stale
+            step = None
         if step is None:
             self._graph_seen[key] += 1
             if self._graph_seen[key] <= 2:
@@ -372,6 +380,11 @@ class OnlineLearner:
         else:
             self._graphed[key] = self._graphed.pop(key)           # mark as most recently used
         return step.replay(self, metrics, logs, labels)
+
+    def _drop_recordings(self) -> None:
+        for old in self._graphed.values():
+            self.optimizer.recycle_table_host(old._keep[0])
+        self._graphed.clear()
 
     def _remember(self, sample: DatasetSample, importance_score: float) -> None:
         """memory_buffer.add (online_learner.py:338), plus the sample's device copy when device_replay is on."""

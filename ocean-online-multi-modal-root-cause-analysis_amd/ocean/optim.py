@@ -40,6 +40,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._lr_host: Optional[float] = None
         self._table_host = None
         self._table_free: list = []          # pinned table buffers of dropped recordings (see _CAPTURED_PINNED)
+        self.generation = 0                  # bumped when the state tensors are replaced (load_state_dict)
 
     def _build_table(self, entries, device):
         rows = []
@@ -103,6 +104,11 @@ class FusedAdam(torch.optim.Optimizer):
         for st in self.state.values():
             if st and torch.is_tensor(st.get("step")):
                 st["step"] = int(st["step"])
+        # the moment tensors are new objects and the step counts may differ: the chunk table, the device-side
+        # mirrors and every recorded step that points at the old tensors are stale from here on
+        self._table_key = None
+        self._step_dev = self._lr_dev = self._lr_host = None
+        self.generation += 1
 
     def sync_lr(self) -> None:
         if self._lr_dev is not None:

@@ -137,3 +137,54 @@ def test_recorded_steps_are_bounded_least_recently_used_first():
     assert [k[0][0] for k in learner._graphed] == [4, 3]
     r = learner.process_tensors(data[2][0], sg, data[2][1], data[2][2])  # seen before: recorded again at once, batch 4 goes
     assert [k[0][0] for k in learner._graphed] == [3, 2] and r["update_count"] == 14
+
+
+def test_recordings_do_not_survive_a_checkpoint_load(tmp_path):
+    """load_checkpoint replaces the optimizer's moment tensors and step counts (online_learner.py:543-565 does the
+    same through torch.optim.Adam.load_state_dict): a step recorded before the load would keep updating the old
+    tensors.  Save after 4 steps, go on to 6, load, go on to 8: the replaying learner must land where the eager one does."""
+    sg = _graph()
+    final = {}
+    for use_graph in (False, True):
+        m, learner = _learner(True, use_graph)
+        path = str(tmp_path / f"ckpt_{use_graph}.pt")
+        for i in range(6):
+            learner.process_tensors(*(lambda d: (d[0], sg, d[1], d[2]))(_data(i)))
+            if i == 3:
+                learner.save_checkpoint(path)
+        n_before = len(learner._graphed)
+        learner.load_checkpoint(path)
+        assert learner.update_count == 4
+        for i in range(4, 8):
+            r = learner.process_tensors(*(lambda d: (d[0], sg, d[1], d[2]))(_data(i)))
+        assert r["update_count"] == 8
+        if use_graph:
+            assert n_before == 1 and len(learner._graphed) == 1
+            assert next(iter(learner._graphed.values())).generation == learner.optimizer.generation == 1
+        st = learner.optimizer.state_dict()["state"]
+        assert all(int(v["step"]) == 8 for v in st.values())
+        final[use_graph] = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for k, v in final[False].items():
+        w = final[True][k]
+        scale = max(v.double().abs().max().item(), 1e-3)
+        assert (v.double() - w.double()).abs().max().item() <= 2e-3 * scale, k
+
+
+def test_freezing_a_component_is_not_replayed_over():
+    """OCEANModel.freeze_component (ocean_model.py:410-452) after a step has been recorded: the recording updates every
+    parameter it was recorded with, so the frozen set is part of what a recording is keyed on."""
+    sg = _graph()
+    m, learner = _learner(True, True)
+    metrics, logs, labels = _data(0)
+    for _ in range(4):
+        learner.process_tensors(metrics, sg, logs, labels)
+    assert len(learner._graphed) == 1
+    m.freeze_component("temporal")
+    frozen = {k: v.detach().clone() for k, v in m.temporal_encoder.named_parameters()}
+    head = m.prediction_head[0].weight.detach().clone()
+    for _ in range(4):
+        learner.process_tensors(metrics, sg, logs, labels)
+    assert len(learner._graphed) == 2                      # a second recording, for the new trainable set
+    for k, v in m.temporal_encoder.named_parameters():
+        assert torch.equal(v, frozen[k]), k
+    assert not torch.equal(m.prediction_head[0].weight, head)
