@@ -325,22 +325,26 @@ __global__ void bn_bwd_param_kernel(const double* __restrict__ bslots, double* _
   if (dgamma) dgamma[c] += (float)sx;
 }
 
-// [Co][Ci][Kt] -> [Kt][Co][Ci]
-__global__ void repack_w_kernel(const float* __restrict__ w, float* __restrict__ wp, int Co, int Ci, int Kt) {
-  const long n = (long)Co * Ci * Kt;
+// Per-tap weight layouts of all convolution blocks in one launch (blockIdx.y = block):
+// w [Co][Ci][Kt] -> wp [Kt][Co][Ci] before the forward pass; dw [Co][Ci][Kt] += dwp [Kt][Co][Ci] after the backward pass.
+struct RepackSet { const float* src; float* dst; int Co, Ci; };
+struct RepackBatch { RepackSet s[OCEAN_MAX_CONV_LAYERS]; };
+__global__ void repack_w_kernel(const RepackBatch b, int Kt) {
+  const RepackSet r = b.s[blockIdx.y];
+  const long n = (long)r.Co * r.Ci * Kt;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int t = (int)(i % Kt);
     const long oc = i / Kt;          // co*Ci + ci
-    wp[(long)t * Co * Ci + oc] = w[i];
+    r.dst[(long)t * r.Co * r.Ci + oc] = r.src[i];
   }
 }
-// dw[Co][Ci][Kt] += dwp[Kt][Co][Ci]
-__global__ void unpack_dw_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Co, int Ci, int Kt) {
-  const long n = (long)Co * Ci * Kt;
+__global__ void unpack_dw_kernel(const RepackBatch b, int Kt) {
+  const RepackSet r = b.s[blockIdx.y];
+  const long n = (long)r.Co * r.Ci * Kt;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int t = (int)(i % Kt);
     const long oc = i / Kt;
-    dw[i] += dwp[(long)t * Co * Ci + oc];
+    r.dst[i] += r.src[(long)t * r.Co * r.Ci + oc];
   }
 }
 
@@ -459,12 +463,15 @@ int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* para
   for (int ph = phase_lo; ph < phase_hi; ++ph) {
     if (ph == 0) {
       if (s->training) OCEAN_TRY(zero_f32(ws + pl.stats[0], pl.wp[0] - pl.stats[0], st));
+      RepackBatch rb;
+      long biggest = 0;
       for (int i = 0; i < L; ++i) {
         const int C = s->channels[i];
-        hipLaunchKernelGGL(repack_w_kernel, dim3(egrid((long)C * C * s->kernel_size)), dim3(256), 0, st,
-                           params[pi_block(i, 0)], ws + pl.wp[i], C, C, s->kernel_size);
-        OCEAN_LAUNCH_CHECK();
+        rb.s[i] = RepackSet{params[pi_block(i, 0)], ws + pl.wp[i], C, C};
+        if ((long)C * C * s->kernel_size > biggest) biggest = (long)C * C * s->kernel_size;
       }
+      hipLaunchKernelGGL(repack_w_kernel, dim3(egrid(biggest), L), dim3(256), 0, st, rb, s->kernel_size);
+      OCEAN_LAUNCH_CHECK();
       OCEAN_TRY(linear_fwd(x, s->F, params[0], params[1], ws + pl.h0, s->channels[0], pl.M, s->channels[0], s->F, 0, st));
       OCEAN_TRY(conv_fwd(pl, s, 0, ws + pl.h0, params, ws, ph + 1 >= phase_hi, st));
     } else {
@@ -570,9 +577,7 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
       g.C = wb + pl.dwp[i]; g.ldc = Cin; g.M = C; g.N = Cin; g.K = M; g.split_k = 0;
       g.taps = k; g.tap_stride_c = (long)C * Cin;
       if (k > 1) { g.T = s->T; g.shift0 = -(k / 2) * d; g.shift_step = d; }
-      OCEAN_TRY(ocean_launch_gemm(g, st));
-      hipLaunchKernelGGL(unpack_dw_kernel, dim3(egrid((long)C * Cin * k)), dim3(256), 0, st, wb + pl.dwp[i], grads[pi_block(i, 0)], C, Cin, k);
-      OCEAN_LAUNCH_CHECK();
+      OCEAN_TRY(ocean_launch_gemm(g, st));       // (the packed gradients of all blocks are unpacked together at the end)
       // data gradient: taps with the opposite shift, plus the identity-residual gradient
       GemmP h = gemm_defaults();
       h.A = dU; h.lda = C; h.B = wf + pl.wp[i]; h.ldb = Cin; h.b_kn = 1; h.M = M; h.N = Cin; h.K = C;
@@ -595,6 +600,16 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
       const int C0 = s->channels[0];
       OCEAN_TRY(linear_bwd_weight(dh0, C0, x, s->F, grads[0], M, C0, s->F, st, grads[1]));   // + bias gradient (column sums of the same operand)
       if (dx) OCEAN_TRY(linear_bwd_data(dh0, C0, params[0], dx, s->F, M, C0, s->F, 0, st));
+      // last phase: every block's per-tap weight gradient is complete
+      RepackBatch rb;
+      long biggest = 0;
+      for (int i = 0; i < L; ++i) {
+        const int Cb = s->channels[i];
+        rb.s[i] = RepackSet{wb + pl.dwp[i], grads[pi_block(i, 0)], Cb, Cb};
+        if ((long)Cb * Cb * s->kernel_size > biggest) biggest = (long)Cb * Cb * s->kernel_size;
+      }
+      hipLaunchKernelGGL(unpack_dw_kernel, dim3(egrid(biggest), L), dim3(256), 0, st, rb, s->kernel_size);
+      OCEAN_LAUNCH_CHECK();
     }
   }
   return OCEAN_OK;
