@@ -105,6 +105,11 @@ int ocean_dcnn_num_phases(const ocean_dcnn_shape* s);
 int ocean_dcnn_stats_block(const ocean_dcnn_shape* s, int phase, int backward,
                            size_t* offset_floats, int* n_doubles);
 
+/* Offset (in floats, into the forward workspace) and width C of dilated block `block`'s output activation
+ * [B*T, C] (after BatchNorm, ReLU, dropout and the residual), valid after ocean_dcnn_fwd.  It is what
+ * DilatedCNN.get_temporal_features pools per layer (dilated_cnn.py:243-277). */
+int ocean_dcnn_block_output(const ocean_dcnn_shape* s, int block, size_t* offset_floats, int* width);
+
 int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* params,
                    float* ws, size_t ws_floats, float* out /* [B,out_dim] */,
                    int phase_lo, int phase_hi, void* stream);
@@ -142,6 +147,15 @@ typedef struct {
  * att_dst [D], bias [D or D/H]; then output_projection.weight [D, D/H], .bias [D].  grads: same order. */
 size_t ocean_gnn_fwd_workspace(const ocean_gnn_shape* s);
 size_t ocean_gnn_bwd_workspace(const ocean_gnn_shape* s);
+/* Offset (floats, into the forward workspace) and width of GAT layer `layer`'s output [R*N, width] (after ReLU, dropout
+ * and the residual), valid after ocean_gnn_fwd: the node embeddings GraphNeuralNetwork.get_node_embeddings returns
+ * (graph_neural_network.py:320-356). */
+int ocean_gnn_layer_output(const ocean_gnn_shape* s, int layer, size_t* offset_floats, int* width);
+/* Which kernel family the edge phase (scores, edge softmax, aggregation) of this shape runs on: 2 = one block per
+ * replica / node range with the per-node tables and CSR in LDS (small graphs), 1 = one node per wave with edge-parallel
+ * lanes reading CSR from memory (graphs whose tables exceed 64 KB of LDS), 0 = generic one-edge-at-a-time kernels
+ * (head counts / widths the other two do not cover); -1 = bad shape.  No counterpart in the reference. */
+int ocean_gnn_edge_kernel_family(const ocean_gnn_shape* s);
 int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features /* [N,G] */, const int* const* graph,
                   float* const* params, float* ws, size_t ws_floats, float* out /* [R*N/pool_n, D] */, void* stream);
 int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const int* const* graph,
@@ -219,6 +233,15 @@ int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const f
                       size_t ws_bwd_floats, const float* dloss /* device scalar or NULL (=1) */, float* d_anchor /* [B,P] */,
                       float* d_positive /* [Bp,P] */, void* stream);
 
+/* reduction='none' of InfoNCELoss (graph_fusion.py:100, 160: F.cross_entropy(..., reduction=self.reduction)): the same
+ * computation with one loss value per anchor row written to row_loss[B] (overwritten, not accumulated; mean_rows is
+ * ignored), and a backward that takes one incoming gradient per row. */
+int ocean_infonce_rows_fwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, const float* negatives,
+                           float* ws, size_t ws_floats, float* row_loss /* [B] */, void* stream);
+int ocean_infonce_rows_bwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, float* ws, float* ws_bwd,
+                           size_t ws_bwd_floats, const float* d_row_loss /* [B] */, float* d_anchor, float* d_positive,
+                           void* stream);
+
 /* The three in-batch pairs of ContrastiveLearningModule.forward in one call (graph_fusion.py:231-249 builds the pairs
  * (temporal, spatial), (temporal, log), (spatial, log) and calls InfoNCELoss.forward, :112-162, on each).
  * Z [3, B, P] holds the three projections; losses[q] is ACCUMULATED (+= mean over B rows) for pair q in that order.
@@ -275,6 +298,11 @@ int ocean_head_bwd(const ocean_head_shape* s, const float* x, float* const* para
 int ocean_bce_fwd(const float* probs, const float* targets, long n, long mean_n, float* loss, void* stream);
 int ocean_bce_bwd(const float* probs, const float* targets, const float* dloss /* device scalar or NULL */,
                   long n, long mean_n, float* d_probs, void* stream);
+
+/* F.binary_cross_entropy(probs, targets, reduction='none') (ocean_model.py:249-253 with compute_loss(reduction='none')):
+ * out[i] = -(y log p + (1-y) log(1-p)), log terms clamped at -100; d_probs[i] = d_out[i] * dBCE/dp. */
+int ocean_bce_elem_fwd(const float* probs, const float* targets, long n, float* out, void* stream);
+int ocean_bce_elem_bwd(const float* probs, const float* targets, const float* d_out, long n, float* d_probs, void* stream);
 
 /* Extra terms of the Trainer's LossFunction (ocean/models/training/trainer.py:90-110):
  * nn.MSELoss between two [n] tensors (gradient to `a` only), and the feature-diversity loss

@@ -450,6 +450,15 @@ int ocean_dcnn_stats_block(const ocean_dcnn_shape* s, int phase, int backward, s
   return OCEAN_OK;
 }
 
+int ocean_dcnn_block_output(const ocean_dcnn_shape* s, int block, size_t* offset_floats, int* width) {
+  DcnnPlan p;
+  OCEAN_TRY(make_plan(s, &p));
+  if (block < 0 || block >= s->L) return OCEAN_ERR_BAD_SHAPE;
+  if (offset_floats) *offset_floats = p.a[2 * block];      // BN layers alternate block, transition, block, ...
+  if (width) *width = p.width[2 * block];
+  return OCEAN_OK;
+}
+
 int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* params, float* ws, size_t ws_floats,
                    float* out, int phase_lo, int phase_hi, void* stream) {
   DcnnPlan pl;

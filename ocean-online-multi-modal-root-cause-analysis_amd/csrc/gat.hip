@@ -1275,6 +1275,21 @@ size_t ocean_gnn_bwd_workspace(const ocean_gnn_shape* s) {
   return make_plan(s, &p) == OCEAN_OK ? p.bwd_total : 0;
 }
 
+int ocean_gnn_layer_output(const ocean_gnn_shape* s, int layer, size_t* offset_floats, int* width) {
+  GnnPlan p;
+  OCEAN_TRY(make_plan(s, &p));
+  if (layer < 0 || layer >= p.layers) return OCEAN_ERR_BAD_SHAPE;
+  if (offset_floats) *offset_floats = p.y[layer];
+  if (width) *width = p.out_dim[layer];
+  return OCEAN_OK;
+}
+
+int ocean_gnn_edge_kernel_family(const ocean_gnn_shape* s) {
+  GnnPlan p;
+  if (make_plan(s, &p) != OCEAN_OK) return -1;
+  return tile_edges(p, s->E) ? 2 : (fast_edges(p) ? 1 : 0);
+}
+
 int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features, const int* const* graph, float* const* params,
                   float* ws, size_t ws_floats, float* out, void* stream) {
   GnnPlan pl;

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a
 // r has label label0 + label_step * r
 __global__ __launch_bounds__(256) void nce_rows_fwd_kernel(const float* __restrict__ sim, int ld, int B, int K, int label0, int label_step,
                                                            float inv_tau, float inv_rows, float* __restrict__ lse_out,
-                                                           float* __restrict__ loss, int group) {
+                                                           float* __restrict__ loss, int group, float* __restrict__ row_loss = nullptr) {
   __shared__ float red[kWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x * kWaves + wave;
   float contrib = 0.f;
@@ -57,7 +57,12 @@ __global__ __launch_bounds__(256) void nce_rows_fwd_kernel(const float* __restri
     const int label = label0 + label_step * (group > 0 ? b % group : b);
     contrib = (lse - r[label] * inv_tau) * inv_rows;
     if (lane == 0) lse_out[b] = lse;
+    if (row_loss != nullptr) {                // reduction='none': the row's own loss, nothing summed (block-uniform branch)
+      if (lane == 0) row_loss[b] = lse - r[label] * inv_tau;
+      contrib = 0.f;
+    }
   }
+  if (row_loss != nullptr) return;
   if (lane == 0) red[wave] = contrib;
   __syncthreads();
   // one add per block (same-address atomics serialise: one per row cost 46 us at 3 x 1024 rows); a block whose rows
@@ -73,11 +78,11 @@ __global__ __launch_bounds__(256) void nce_rows_fwd_kernel(const float* __restri
 // sim[b,k] <- (softmax_k(sim/tau) - [k == label_b]) * dloss * inv_rows * inv_tau
 __global__ __launch_bounds__(256) void nce_rows_bwd_kernel(float* __restrict__ sim, int ld, int B, int K, int label0, int label_step,
                                                            float inv_tau, float inv_rows, const float* __restrict__ lse,
-                                                           const float* __restrict__ dloss, int group) {
+                                                           const float* __restrict__ dloss, int group, int dloss_per_row = 0) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (b >= B) return;
   float* r = sim + (long)b * ld;
-  const float g = (dloss ? dloss[group > 0 ? b / group : 0] : 1.0f) * inv_rows * inv_tau;
+  const float g = (dloss ? dloss[dloss_per_row ? b : (group > 0 ? b / group : 0)] : 1.0f) * inv_rows * inv_tau;
   const float l = lse[b];
   const int label = label0 + label_step * (group > 0 ? b % group : b);
   for (int k = lane; k < K; k += 64) r[k] = (__expf(r[k] * inv_tau - l) - (k == label ? 1.f : 0.f)) * g;
@@ -128,6 +133,19 @@ __global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restr
   const float g = (dloss ? dloss[0] : 1.0f) * inv_n;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     dp[i] = g * (p[i] - y[i]) / fmaxf(p[i] * (1.0f - p[i]), 1e-12f);
+}
+
+// reduction='none': out[i] = -(y log p + (1-y) log(1-p)), same clamps; dp[i] = dout[i] * (p - y) / max(p (1-p), 1e-12)
+__global__ void bce_elem_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y, long n, float* __restrict__ out) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float lp = fmaxf(logf(p[i]), -100.f), lq = fmaxf(log1pf(-p[i]), -100.f);
+    out[i] = -(y[i] * lp + (1.0f - y[i]) * lq);
+  }
+}
+__global__ void bce_elem_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y, const float* __restrict__ dout, long n,
+                                    float* __restrict__ dp) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dp[i] = dout[i] * (p[i] - y[i]) / fmaxf(p[i] * (1.0f - p[i]), 1e-12f);
 }
 
 // loss += mean((a-b)^2)
@@ -201,11 +219,11 @@ size_t ocean_infonce_bwd_workspace(const ocean_infonce_shape* s) {
   return s ? al4((size_t)s->B * s->P) + al4((size_t)s->Bp * s->P) : 0;
 }
 
-int ocean_infonce_fwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, const float* negatives,
-                      float* ws, size_t ws_floats, float* loss, void* stream) {
+static int infonce_fwd_impl(const ocean_infonce_shape* s, const float* anchor, const float* positive, const float* negatives,
+                            float* ws, size_t ws_floats, float* loss, float* row_loss, void* stream) {
   NcePlan pl;
   OCEAN_TRY(nce_plan(s, &pl));
-  if (!anchor || !positive || !ws || !loss || (s->K > 0 && !negatives)) return OCEAN_ERR_NULL;
+  if (!anchor || !positive || !ws || (!loss && !row_loss) || (s->K > 0 && !negatives)) return OCEAN_ERR_NULL;
   if (ws_floats < pl.total) return OCEAN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int B = s->B, P = s->P, K = s->K;
@@ -222,32 +240,43 @@ int ocean_infonce_fwd(const ocean_infonce_shape* s, const float* anchor, const f
     g.A = ws + pl.ah; g.lda = P; g.B = ws + pl.nh; g.ldb = P; g.C = ws + pl.sim + 4; g.ldc = pl.ldsim; g.M = B; g.N = K; g.K = P;
     OCEAN_TRY(ocean_launch_gemm(g, st));
     hipLaunchKernelGGL(nce_rows_fwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.sim + 3, pl.ldsim, B, K + 1, 0, 0, inv_tau,
-                       inv_rows, ws + pl.lse, loss, 0);
+                       inv_rows, ws + pl.lse, loss, 0, row_loss);
   } else {
     GemmP g = gemm_defaults();
     g.A = ws + pl.ah; g.lda = P; g.B = ws + pl.ph; g.ldb = P; g.C = ws + pl.sim; g.ldc = pl.ldsim; g.M = B; g.N = s->Bp; g.K = P;
     OCEAN_TRY(ocean_launch_gemm(g, st));
     hipLaunchKernelGGL(nce_rows_fwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.sim, pl.ldsim, B, s->Bp, s->label_offset, 1,
-                       inv_tau, inv_rows, ws + pl.lse, loss, 0);
+                       inv_tau, inv_rows, ws + pl.lse, loss, 0, row_loss);
   }
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }
 
-int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, float* ws, float* wb,
-                      size_t wb_floats, const float* dloss, float* d_anchor, float* d_positive, void* stream) {
+int ocean_infonce_fwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, const float* negatives,
+                      float* ws, size_t ws_floats, float* loss, void* stream) {
+  if (!loss) return OCEAN_ERR_NULL;
+  return infonce_fwd_impl(s, anchor, positive, negatives, ws, ws_floats, loss, nullptr, stream);
+}
+int ocean_infonce_rows_fwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, const float* negatives,
+                           float* ws, size_t ws_floats, float* row_loss, void* stream) {
+  if (!row_loss) return OCEAN_ERR_NULL;
+  return infonce_fwd_impl(s, anchor, positive, negatives, ws, ws_floats, nullptr, row_loss, stream);
+}
+
+static int infonce_bwd_impl(const ocean_infonce_shape* s, const float* anchor, const float* positive, float* ws, float* wb,
+                            size_t wb_floats, const float* dloss, int per_row, float* d_anchor, float* d_positive, void* stream) {
   NcePlan pl;
   OCEAN_TRY(nce_plan(s, &pl));
   if (!ws || !wb || !d_anchor || !d_positive) return OCEAN_ERR_NULL;
   if (wb_floats < ocean_infonce_bwd_workspace(s)) return OCEAN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int B = s->B, P = s->P, K = s->K, Bp = s->Bp;
-  const float inv_tau = 1.0f / s->tau, inv_rows = 1.0f / (float)(s->mean_rows > 0 ? s->mean_rows : B);
+  const float inv_tau = 1.0f / s->tau, inv_rows = per_row ? 1.0f : 1.0f / (float)(s->mean_rows > 0 ? s->mean_rows : B);
   float* dah = wb; float* dph = wb + al4((size_t)B * P);
   if (K > 0) {
     float* sim = ws + pl.sim + 3;
     hipLaunchKernelGGL(nce_rows_bwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, sim, pl.ldsim, B, K + 1, 0, 0, inv_tau, inv_rows,
-                       ws + pl.lse, dloss, 0);
+                       ws + pl.lse, dloss, 0, per_row);
     OCEAN_LAUNCH_CHECK();
     // d a_hat = dL[:,0] * p_hat + dL[:,1:] . n_hat ;  d p_hat = dL[:,0] * a_hat
     OCEAN_TRY(linear_bwd_data(sim + 1, pl.ldsim, ws + pl.nh, dah, P, B, K, P, 0, st));
@@ -258,7 +287,7 @@ int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const f
   } else {
     float* sim = ws + pl.sim;
     hipLaunchKernelGGL(nce_rows_bwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, sim, pl.ldsim, B, Bp, s->label_offset, 1, inv_tau,
-                       inv_rows, ws + pl.lse, dloss, 0);
+                       inv_rows, ws + pl.lse, dloss, 0, per_row);
     OCEAN_LAUNCH_CHECK();
     OCEAN_TRY(linear_bwd_data(sim, pl.ldsim, ws + pl.ph, dah, P, B, Bp, P, 0, st));      // [B,Bp] . [Bp,P]
     OCEAN_TRY(zero_f32(dph, (size_t)Bp * P, st));
@@ -267,6 +296,16 @@ int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const f
   OCEAN_TRY(l2norm_bwd(dah, P, ws + pl.ah, P, ws + pl.na, d_anchor, P, B, P, 1e-12f, st));
   OCEAN_TRY(l2norm_bwd(dph, P, ws + pl.ph, P, ws + pl.np, d_positive, P, Bp, P, 1e-12f, st));
   return OCEAN_OK;
+}
+
+int ocean_infonce_bwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, float* ws, float* wb,
+                      size_t wb_floats, const float* dloss, float* d_anchor, float* d_positive, void* stream) {
+  return infonce_bwd_impl(s, anchor, positive, ws, wb, wb_floats, dloss, 0, d_anchor, d_positive, stream);
+}
+int ocean_infonce_rows_bwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, float* ws, float* wb,
+                           size_t wb_floats, const float* d_row_loss, float* d_anchor, float* d_positive, void* stream) {
+  if (!d_row_loss) return OCEAN_ERR_NULL;
+  return infonce_bwd_impl(s, anchor, positive, ws, wb, wb_floats, d_row_loss, 1, d_anchor, d_positive, stream);
 }
 
 // ---------------------------------------------------------------- the three in-batch pairs at once
@@ -555,6 +594,21 @@ int ocean_bce_bwd(const float* probs, const float* targets, const float* dloss, 
   if (!probs || !targets || !dprobs) return OCEAN_ERR_NULL;
   hipLaunchKernelGGL(bce_bwd_kernel, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, probs, targets, dloss, n,
                      1.0f / (float)(mean_n > 0 ? mean_n : n), dprobs);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int ocean_bce_elem_fwd(const float* probs, const float* targets, long n, float* out, void* stream) {
+  if (!probs || !targets || !out) return OCEAN_ERR_NULL;
+  if (n <= 0) return OCEAN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(bce_elem_fwd_kernel, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, probs, targets, n, out);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+int ocean_bce_elem_bwd(const float* probs, const float* targets, const float* dout, long n, float* dprobs, void* stream) {
+  if (!probs || !targets || !dout || !dprobs) return OCEAN_ERR_NULL;
+  if (n <= 0) return OCEAN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(bce_elem_bwd_kernel, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, probs, targets, dout, n, dprobs);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }

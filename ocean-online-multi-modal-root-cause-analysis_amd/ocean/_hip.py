@@ -138,6 +138,13 @@ def _declare_rest(lib) -> None:
     sig("ocean_diversity_workspace", c_size_t, c_int, c_int)
     sig("ocean_diversity_fwd", c_int, vp, c_int, c_int, vp, c_size_t, vp, vp)
     sig("ocean_diversity_bwd", c_int, c_int, c_int, vp, vp, vp, vp)
+    sig("ocean_infonce_rows_fwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp)
+    sig("ocean_infonce_rows_bwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp, vp, vp)
+    sig("ocean_bce_elem_fwd", c_int, vp, vp, c_long, vp, vp)
+    sig("ocean_bce_elem_bwd", c_int, vp, vp, vp, c_long, vp, vp)
+    sig("ocean_dcnn_block_output", c_int, POINTER(DcnnShape), c_int, POINTER(c_size_t), POINTER(c_int))
+    sig("ocean_gnn_layer_output", c_int, POINTER(GnnShape), c_int, POINTER(c_size_t), POINTER(c_int))
+    sig("ocean_gnn_edge_kernel_family", c_int, POINTER(GnnShape))
     sig("ocean_prof_enable", c_int, c_int)
     sig("ocean_clear_last_error", c_int)
     sig("ocean_prof_summary", c_int, ctypes.c_char_p, c_size_t)

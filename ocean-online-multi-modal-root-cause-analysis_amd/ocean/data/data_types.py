@@ -35,7 +35,23 @@ class ServiceGraph:
         return self.node_features.size(1)
 
     def to_edge_index(self) -> torch.Tensor:
-        return torch.nonzero(self.adjacency_matrix, as_tuple=False).t().contiguous()
+        """[2, E] (source row, target row) of the non-zero entries (data_types.py:197-199).  A sparse COO adjacency
+        (large service graphs: 4096 services are 64 MB dense, ~0.5 MB as an edge list) gives its stored non-zeros
+        in the same row-major order, and no dense matrix is ever formed."""
+        adj = self.adjacency_matrix
+        if adj.is_sparse:
+            adj = adj.coalesce()
+            return adj.indices()[:, adj.values() != 0].contiguous()
+        return torch.nonzero(adj, as_tuple=False).t().contiguous()
+
+    @staticmethod
+    def from_edge_index(edge_index: torch.Tensor, num_services: int, node_features: torch.Tensor,
+                        service_names: Optional[List[str]] = None) -> "ServiceGraph":
+        """A graph given as an edge list [2, E] (row 0 = source, row 1 = target); the adjacency is kept as a sparse
+        COO tensor.  No counterpart in the reference, whose graph builder always emits a dense matrix."""
+        ei = edge_index.detach().to("cpu", torch.long)
+        adj = torch.sparse_coo_tensor(ei, torch.ones(ei.shape[1]), (num_services, num_services)).coalesce()
+        return ServiceGraph(adjacency_matrix=adj, node_features=node_features, service_names=service_names)
 
 
 @dataclass

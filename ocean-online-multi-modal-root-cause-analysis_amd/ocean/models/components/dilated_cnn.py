@@ -211,6 +211,42 @@ class DilatedCNN(nn.Module):
                 torch._foreach_add_([bn.num_batches_tracked for bn in self._bn_modules()], 1)   # one launch for all layers
         return out
 
+    def get_temporal_features(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """The output of every dilated block pooled over time, one [B, C_i] tensor per block (dilated_cnn.py:243-277;
+        the reference pools with max only when global_pooling == 'max', which has no HIP implementation, so: mean).
+        Runs the fused forward and pools the block activations it leaves in its workspace; the result carries no
+        gradient.  In training mode the BatchNorm running statistics advance, as a forward pass of the reference's
+        blocks would advance them."""
+        if x.dim() != 3 or x.shape[2] != self.input_dim:
+            raise ValueError(f"expected metrics of shape (batch, seq_len, {self.input_dim}), got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        L = _hip.lib()
+        with torch.no_grad():
+            shape = self._shape(x)
+            ws = torch.empty(L.ocean_dcnn_fwd_workspace(ctypes.byref(shape)), device=x.device, dtype=torch.float32)
+            out = torch.empty(shape.B, shape.out_dim, device=x.device, dtype=torch.float32)
+            params = self._param_list()
+            nph = L.ocean_dcnn_num_phases(ctypes.byref(shape))
+            sync = self.stats_all_reduce if shape.training else None
+            for lo, hi in ([(0, nph)] if sync is None else [(p, p + 1) for p in range(nph)]):
+                _hip.check(L.ocean_dcnn_fwd(ctypes.byref(shape), _hip.dev_ptr(x, "metrics"), _hip.ptr_table(params, "dcnn param"),
+                                            _hip.dev_ptr(ws), ws.numel(), _hip.dev_ptr(out), lo, hi, _hip.stream()), "ocean_dcnn_fwd")
+                if sync is not None and hi < nph:
+                    sync(self._stats_view(shape, ws, lo, False))
+            feats = []
+            for i in range(shape.L):
+                off, width = ctypes.c_size_t(0), ctypes.c_int(0)
+                _hip.check(L.ocean_dcnn_block_output(ctypes.byref(shape), i, ctypes.byref(off), ctypes.byref(width)),
+                           "ocean_dcnn_block_output")
+                act = ws[off.value: off.value + shape.B * shape.T * width.value].view(shape.B, shape.T, width.value)
+                pooled = torch.empty(shape.B, width.value, device=x.device, dtype=torch.float32)
+                _hip.check(L.ocean_mean_mid_f32(_hip.dev_ptr(act), _hip.dev_ptr(pooled), shape.B, shape.T, width.value,
+                                                _hip.stream()), "ocean_mean_mid_f32")
+                feats.append(pooled)
+            if self.training:
+                torch._foreach_add_([bn.num_batches_tracked for bn in self._bn_modules()], 1)
+        return feats
+
     def compute_receptive_field(self) -> int:
         return 1 + sum((self.kernel_size - 1) * d for d in self.dilation_rates)
 

@@ -56,8 +56,10 @@ class InfoNCELoss(nn.Module):
         self.temperature, self.reduction = temperature, reduction
 
     def forward(self, anchor: torch.Tensor, positive: torch.Tensor, negative: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if self.reduction not in ("mean", "sum"):
-            raise NotImplementedError("reduction='none' is not provided by the fused kernel")
+        if self.reduction not in ("mean", "sum", "none"):
+            raise ValueError(f"{self.reduction} is not a valid value for reduction")
+        if self.reduction == "none":              # F.cross_entropy(..., reduction='none'): one value per anchor row
+            return ops.infonce(anchor, positive, negative, self.temperature, per_row=True)
         loss = ops.infonce(anchor, positive, negative, self.temperature)
         return loss * anchor.shape[0] if self.reduction == "sum" else loss
 

@@ -52,8 +52,24 @@ class DeviceGraph:
     @staticmethod
     def from_adjacency(adj: torch.Tensor, device) -> "DeviceGraph":
         # ServiceGraph.to_edge_index (ocean/data/data_types.py:197-199): row = source, column = target
-        ei = torch.nonzero(adj.detach().to("cpu"), as_tuple=False).t().contiguous()
+        adj = adj.detach().to("cpu")
+        if adj.is_sparse:                     # edge list straight to CSR: no dense [N, N] matrix for large graphs
+            adj = adj.coalesce()
+            ei = adj.indices()[:, adj.values() != 0].contiguous()
+        else:
+            ei = torch.nonzero(adj, as_tuple=False).t().contiguous()
         return DeviceGraph(ei, adj.shape[0], device)
+
+    @staticmethod
+    def from_edge_index(edge_index: torch.Tensor, num_nodes: int, device) -> "DeviceGraph":
+        """[2, E] (source, target) -> device CSR pair."""
+        return DeviceGraph(edge_index, num_nodes, device)
+
+    @staticmethod
+    def tensor_key(adj: torch.Tensor):
+        """(storage address, version, shape) of an adjacency tensor, dense or sparse COO: what caches key on."""
+        base = adj._indices() if adj.is_sparse else adj
+        return (base.data_ptr(), adj._version, tuple(adj.shape), bool(adj.is_sparse))
 
 
 class GATConv(nn.Module):
@@ -199,6 +215,37 @@ class GraphNeuralNetwork(nn.Module):
             pool_n = n // nb
         graph = DeviceGraph(edge_index, n, x.device)
         return _GnnFunction.apply(x.contiguous().float(), self, graph, 1, pool_n, *self._param_list())
+
+    def get_node_embeddings(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+        """Node-level output of the last GAT layer, without pooling and output projection
+        (graph_neural_network.py:320-356): [n, hidden // heads] as OCEANModel builds the encoder (its last layer
+        averages the heads).  Read from the fused forward's workspace; carries no gradient."""
+        self._check_supported()
+        L = _hip.lib()
+        with torch.no_grad():
+            x = x.contiguous().float()
+            graph = DeviceGraph(edge_index, x.shape[0], x.device)
+            s = self._shape(x, graph, 1, 0)
+            ws = torch.empty(L.ocean_gnn_fwd_workspace(ctypes.byref(s)), device=x.device, dtype=torch.float32)
+            out = torch.empty(1, s.D, device=x.device, dtype=torch.float32)
+            _hip.check(L.ocean_gnn_fwd(ctypes.byref(s), _hip.dev_ptr(x, "node_features"), graph.table,
+                                       _hip.ptr_table(self._param_list(), "gnn param"), _hip.dev_ptr(ws), ws.numel(),
+                                       _hip.dev_ptr(out), _hip.stream()), "ocean_gnn_fwd")
+            off, width = ctypes.c_size_t(0), ctypes.c_int(0)
+            _hip.check(L.ocean_gnn_layer_output(ctypes.byref(s), s.layers - 1, ctypes.byref(off), ctypes.byref(width)),
+                       "ocean_gnn_layer_output")
+            return ws[off.value: off.value + x.shape[0] * width.value].view(x.shape[0], width.value).clone()
+
+    def edge_kernel_family(self, graph: DeviceGraph, replicas: int = 1) -> str:
+        """Which kernels the edge phase runs on for this graph: 'replica_block' (per-node tables and CSR staged in LDS;
+        small service graphs), 'node_per_wave' (CSR read from memory; graphs too large for the LDS tables) or 'generic'."""
+        s = _hip.GnnShape()
+        s.N, s.R, s.G, s.D, s.H = graph.num_nodes, replicas, self.input_dim, self.hidden_dim, self.num_heads
+        s.layers, s.E, s.pool_n = self.num_layers, graph.num_edges, 0
+        fam = _hip.lib().ocean_gnn_edge_kernel_family(ctypes.byref(s))
+        if fam < 0:
+            raise _hip.OceanHipError("bad graph shape")
+        return ("generic", "node_per_wave", "replica_block")[fam]
 
     def get_model_info(self) -> dict:
         total = sum(p.numel() for p in self.parameters())

@@ -119,7 +119,7 @@ class OCEANModel(nn.Module):
         """Device CSR of the service graph, built once per (graph object,
         adjacency version, device) and cached on the graph."""
         adj = service_graph.adjacency_matrix
-        key = (adj.data_ptr(), adj._version, tuple(adj.shape), str(self.device))
+        key = DeviceGraph.tensor_key(adj) + (str(self.device),)
         cache = getattr(service_graph, "_ocean_device_graph", None)
         if cache is None or cache[0] != key:
             g = DeviceGraph.from_adjacency(adj, self.device)

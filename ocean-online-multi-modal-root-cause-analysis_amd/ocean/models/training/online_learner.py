@@ -25,6 +25,7 @@ from ...configs import OCEANConfig
 from ...data.data_types import DatasetSample
 from ...optim import FusedAdam
 from ...staging import BatchStager, ReplayPool
+from ..components import DeviceGraph
 from ..ocean_model import OCEANModel
 
 logger = logging.getLogger(__name__)
@@ -147,7 +148,7 @@ class _GraphedStep:
         model, opt = learner.model, learner.optimizer
         dev = model.device
         if opt._step_dev is None:
-            opt.make_capturable(dev)
+            opt.make_capturable(dev, learner._trained_params())
         self.metrics = metrics.detach().to(dev, torch.float32).clone()
         self.logs = logs.detach().to(dev, torch.float32).clone()
         self.labels = labels.detach().to(dev, torch.float32).clone()
@@ -155,6 +156,9 @@ class _GraphedStep:
         self.epoch = _hip.seed_epoch(dev)
         self.generation = opt.generation           # recordings made before a load_state_dict point at replaced tensors
         clip = learner.config.training.gradient_clip_norm
+        # the chunk table of the recorded optimizer step is staged through page-locked memory: allocate that buffer
+        # now, outside the capture (the two eager steps before a recording left a gradient on every trained parameter)
+        opt.reserve_table_host([p for g in opt.param_groups for p in g["params"] if p.grad is not None])
         opt.zero_grad(set_to_none=True)            # gradients are re-created inside the graph's memory pool
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
@@ -167,10 +171,10 @@ class _GraphedStep:
             self.keys = [k for k in ("total_loss", "prediction_loss", "contrastive_loss") if torch.is_tensor(losses.get(k))]
             self.loss_vec = torch.stack([losses[k].detach().float().reshape(()) for k in self.keys])
         self.outputs = outputs
-        # recording advanced the host-side step counters without running anything: undo that
-        for st in opt.state.values():
-            if st:
-                st["step"] -= 1
+        # recording advanced the host-side step counters of the parameters it updates without running anything: undo
+        # that, for those parameters only (a frozen component has state from earlier steps but is not in this step)
+        self.params = [p for g in opt.param_groups for p in g["params"] if p.grad is not None]
+        opt.bump_steps(self.params, -1)
         # buffers the recorded copy nodes and kernels read on every replay
         self._keep = (opt._table_host, opt._table, opt._sq)
 
@@ -180,7 +184,7 @@ class _GraphedStep:
         self.labels.copy_(labels, non_blocking=True)
         learner.optimizer.sync_lr()               # a learning rate the host changed since the last step
         self.graph.replay()
-        learner.optimizer.after_replay()
+        learner.optimizer.after_replay(self.params)
         learner.update_count += 1
         learner._before_readback()
         return dict(zip(self.keys, self.loss_vec.cpu().tolist()))
@@ -220,6 +224,7 @@ class OnlineLearner:
         self._mods = None
         self._prefetched = None
         self._graph_seen: Dict[Any, int] = defaultdict(int)
+        self._replay_warned: set = set()
 
     # ------------------------------------------------------------------ the update step
     def _losses_to_host(self, losses: Dict[str, Any]) -> Dict[str, float]:
@@ -338,25 +343,57 @@ class OnlineLearner:
         return {"batch_loss": host["total_loss"], "batch_prediction_loss": host["prediction_loss"],
                 "batch_size": int(metrics.shape[0]), "learning_rate": current_lr, "update_count": self.update_count}
 
+    def _trained_params(self):
+        """Parameters the next update will change: those that require a gradient and received one on the last step
+        (never-used tensors such as the three unused cross-modal attention modules get none, ever)."""
+        return [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad and p.grad is not None]
+
+    def _replay_ineligible(self) -> Optional[str]:
+        """Why this learner's update step cannot be recorded and replayed as a HIP graph, or None when it can."""
+        if self.model.device.type != "cuda":
+            return "the model is not on a GPU"
+        if not isinstance(self.optimizer, FusedAdam):
+            return "the optimizer is not ocean.optim.FusedAdam (its step is not capturable)"
+        if len(self.optimizer.param_groups) != 1:
+            return "the optimizer has several parameter groups"
+        if self.grad_sync is not None and not getattr(self.grad_sync, "capturable", False):
+            return "a gradient synchronisation hook that cannot be captured is installed"
+        if self.model.contrastive_negatives != "in_batch" and not getattr(
+                self.model.fusion_module.contrastive_module, "device_ring", False):
+            return "memory-bank negatives with the ring pointer kept on the host"
+        if self.optimizer.common_step(self._trained_params()) is None:
+            return "the trained parameters have different Adam step counts (a component was frozen for a while)"
+        return None
+
     def _graph_step(self, metrics, service_graph, logs, labels) -> Optional[Dict[str, float]]:
         """Replay (or, on the third step with one signature, record) the HIP graph of this update; None when the
-        step has to run eagerly."""
-        if (self.grad_sync is not None or not isinstance(self.optimizer, FusedAdam) or self.model.device.type != "cuda"
-                or self.model.contrastive_negatives != "in_batch"):
+        step has to run eagerly (said once per reason in the log)."""
+        why = self._replay_ineligible()
+        if why is not None:
+            if why not in self._replay_warned:
+                self._replay_warned.add(why)
+                logger.warning("use_hip_graph is set but the update step runs as separate launches: %s", why)
             return None
         adj = service_graph.adjacency_matrix
         # everything a recording bakes in: shapes, the graph's tensors, which components train, and the optimizer's
         # by-value hyper-parameters (the learning rate and the step count are read from device memory instead)
         grp = self.optimizer.param_groups[0]
-        key = (tuple(metrics.shape), tuple(logs.shape), tuple(labels.shape), id(service_graph), adj._version,
-               service_graph.node_features._version, getattr(self.model, "trainable_version", 0),
-               tuple(grp["betas"]), grp["eps"], grp["weight_decay"], self.config.training.gradient_clip_norm)
+        nf = service_graph.node_features
+        # a tensor that REPLACES the adjacency or the node features starts again at version 0 under the same graph
+        # object, so the storage addresses and shapes are part of the key as well (OCEANModel.device_graph keys the
+        # device CSR the same way: both paths then pick up a new topology on the same step)
+        key = (tuple(metrics.shape), tuple(logs.shape), tuple(labels.shape), id(service_graph)) + DeviceGraph.tensor_key(adj) + (
+               nf.data_ptr(), nf._version, tuple(nf.shape), getattr(self.model, "trainable_version", 0),
+               tuple(grp["betas"]), grp["eps"], grp["weight_decay"], self.config.training.gradient_clip_norm,
+               self.model.contrastive_negatives)
         step = self._graphed.get(key)
         if step is not None and step.generation != self.optimizer.generation:
             self._drop_recordings()                # the optimizer state was reloaded: every recording is stale
             step = None
         if step is None:
-            self._graph_seen[key] += 1
+            self._graph_seen[key] = self._graph_seen.pop(key, 0) + 1      # re-inserted: most recently seen last
+            while len(self._graph_seen) > 64:                  # bounded: the signature seen longest ago goes first
+                self._graph_seen.pop(next(iter(self._graph_seen)))
             if self._graph_seen[key] <= 2:
                 return None
             before = torch.cuda.current_stream(self.model.device)
@@ -462,14 +499,18 @@ class OnlineLearner:
         return summary
 
     def save_checkpoint(self, filepath: str):
+        # plain Python containers and floats only, so that load_checkpoint can use torch's restricted unpickler
         torch.save({"model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
-                    "update_count": self.update_count, "performance_history": dict(self.performance_history),
-                    "lr_scheduler_state": {"current_lr": self.lr_scheduler.current_lr,
-                                           "performance_history": list(self.lr_scheduler.performance_history),
-                                           "lr_history": self.lr_scheduler.lr_history}}, filepath)
+                    "update_count": int(self.update_count),
+                    "performance_history": {k: [float(x) for x in v] for k, v in self.performance_history.items()},
+                    "lr_scheduler_state": {"current_lr": float(self.lr_scheduler.current_lr),
+                                           "performance_history": [float(x) for x in self.lr_scheduler.performance_history],
+                                           "lr_history": [float(x) for x in self.lr_scheduler.lr_history]}}, filepath)
 
     def load_checkpoint(self, filepath: str):
-        ckpt = torch.load(filepath, map_location=self.model.device, weights_only=False)
+        # weights_only: the file is unpickled with torch's restricted loader (tensors, dicts, lists, numbers, strings),
+        # which is all save_checkpoint - and the reference's (online_learner.py:528-546) - ever writes
+        ckpt = torch.load(filepath, map_location=self.model.device, weights_only=True)
         self.model.load_state_dict(ckpt["model_state_dict"])
         self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
         self.update_count = ckpt["update_count"]

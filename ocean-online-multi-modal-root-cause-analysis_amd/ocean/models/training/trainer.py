@@ -235,9 +235,23 @@ class Trainer:
     # ------------------------------------------------------------------ checkpoints
     def _checkpoint_dict(self, epoch: int, val_loss: float) -> Dict[str, Any]:
         return {"epoch": epoch, "model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
-                "scheduler_state_dict": self.lr_scheduler.scheduler.state_dict(), "val_loss": val_loss,
-                "train_history": dict(self.train_history), "val_history": dict(self.val_history),
-                "config": self.config.to_dict()}
+                "scheduler_state_dict": self._plain(self.lr_scheduler.scheduler.state_dict()), "val_loss": float(val_loss),
+                "train_history": self._plain(dict(self.train_history)), "val_history": self._plain(dict(self.val_history)),
+                "config": self._plain(self.config.to_dict())}
+
+    @staticmethod
+    def _plain(obj):
+        """Tensors stay; numpy scalars become Python numbers, tuples / other containers become lists / dicts, and anything
+        else its repr - so that the checkpoint loads under torch.load(weights_only=True)."""
+        if torch.is_tensor(obj) or obj is None or isinstance(obj, (bool, int, float, str)):
+            return obj
+        if isinstance(obj, np.generic):
+            return obj.item()
+        if isinstance(obj, dict):
+            return {(k if isinstance(k, (str, int, float, bool)) else str(k)): Trainer._plain(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple, set)):
+            return [Trainer._plain(v) for v in obj]
+        return repr(obj)
 
     def _save_checkpoint(self, epoch: int, val_loss: float):
         d = Path(self.config.training.checkpoint_dir)
@@ -254,7 +268,8 @@ class Trainer:
             json.dump({"train_history": dict(self.train_history), "val_history": dict(self.val_history)}, f, indent=2)
 
     def load_checkpoint(self, checkpoint_path: str):
-        ckpt = torch.load(checkpoint_path, map_location=self.device, weights_only=False)
+        # torch's restricted unpickler: checkpoints hold tensors, numbers, strings and plain containers only
+        ckpt = torch.load(checkpoint_path, map_location=self.device, weights_only=True)
         self.model.load_state_dict(ckpt["model_state_dict"])
         self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
         if "scheduler_state_dict" in ckpt:

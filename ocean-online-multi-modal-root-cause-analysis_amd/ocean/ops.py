@@ -45,10 +45,44 @@ class _InfoNce(torch.autograd.Function):
         return da, dp, None, None, None, None
 
 
+class _InfoNceRows(torch.autograd.Function):
+    """reduction='none': one loss per anchor row."""
+
+    @staticmethod
+    def forward(ctx, anchor, positive, negatives, tau, label_offset):
+        L = _hip.lib()
+        sh = _hip.InfoNceShape()
+        sh.B, sh.P = anchor.shape
+        sh.Bp = positive.shape[0]
+        sh.K = 0 if negatives is None else negatives.shape[0]
+        sh.label_offset, sh.mean_rows, sh.tau = label_offset, 0, tau
+        ws = torch.empty(L.ocean_infonce_workspace(ctypes.byref(sh)), device=anchor.device, dtype=torch.float32)
+        rows = torch.empty(sh.B, device=anchor.device, dtype=torch.float32)
+        _hip.check(L.ocean_infonce_rows_fwd(ctypes.byref(sh), _hip.dev_ptr(anchor, "anchor"), _hip.dev_ptr(positive, "positive"),
+                                            _hip.dev_ptr(negatives, "negatives"), _hip.dev_ptr(ws), ws.numel(), _hip.dev_ptr(rows),
+                                            _hip.stream()), "ocean_infonce_rows_fwd")
+        ctx.sh = sh
+        ctx.save_for_backward(anchor, positive, ws)
+        return rows
+
+    @staticmethod
+    def backward(ctx, drows):
+        L = _hip.lib()
+        anchor, positive, ws = ctx.saved_tensors
+        sh = ctx.sh
+        wb = torch.empty(L.ocean_infonce_bwd_workspace(ctypes.byref(sh)), device=anchor.device, dtype=torch.float32)
+        da, dp = torch.empty_like(anchor), torch.empty_like(positive)
+        ws = ws.clone()                          # the backward pass rewrites the saved similarities
+        _hip.check(L.ocean_infonce_rows_bwd(ctypes.byref(sh), _hip.dev_ptr(anchor), _hip.dev_ptr(positive), _hip.dev_ptr(ws),
+                                            _hip.dev_ptr(wb), wb.numel(), _hip.dev_ptr(drows.contiguous().float(), "d_row_loss"),
+                                            _hip.dev_ptr(da), _hip.dev_ptr(dp), _hip.stream()), "ocean_infonce_rows_bwd")
+        return da, dp, None, None, None
+
+
 def infonce(anchor: torch.Tensor, positive: torch.Tensor, negatives: Optional[torch.Tensor] = None,
-            temperature: float = 0.1, label_offset: int = 0, mean_rows: int = 0) -> torch.Tensor:
-    """InfoNCELoss.forward (graph_fusion.py:112-162), reduction='mean'.
-    negatives given: memory-bank branch; None: in-batch branch where row b of
+            temperature: float = 0.1, label_offset: int = 0, mean_rows: int = 0, per_row: bool = False) -> torch.Tensor:
+    """InfoNCELoss.forward (graph_fusion.py:112-162): the mean over rows, or with `per_row` (reduction='none') one
+    value per anchor row.  negatives given: memory-bank branch; None: in-batch branch where row b of
     `anchor` is matched with row label_offset + b of `positive`."""
     if anchor.dim() != 2 or positive.dim() != 2 or anchor.shape[1] != positive.shape[1]:
         raise ValueError("anchor and positive must be [B, dim] with equal dim")
@@ -56,6 +90,9 @@ def infonce(anchor: torch.Tensor, positive: torch.Tensor, negatives: Optional[to
         if positive.shape[0] != anchor.shape[0]:
             raise ValueError("anchor and positive must have the same batch size")
         negatives = negatives.detach().contiguous().float()
+    if per_row:
+        return _InfoNceRows.apply(anchor.contiguous().float(), positive.contiguous().float(), negatives, float(temperature),
+                                  int(label_offset))
     return _InfoNce.apply(anchor.contiguous().float(), positive.contiguous().float(), negatives, float(temperature),
                           int(label_offset), int(mean_rows))
 
@@ -129,13 +166,35 @@ class _Bce(torch.autograd.Function):
         return dp, None, None
 
 
+class _BceElem(torch.autograd.Function):
+    """reduction='none': the per-element loss, same shape as the input."""
+
+    @staticmethod
+    def forward(ctx, probs, targets):
+        out = torch.empty_like(probs)
+        _hip.check(_hip.lib().ocean_bce_elem_fwd(_hip.dev_ptr(probs, "probs"), _hip.dev_ptr(targets, "targets"), probs.numel(),
+                                                 _hip.dev_ptr(out), _hip.stream()), "ocean_bce_elem_fwd")
+        ctx.save_for_backward(probs, targets)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        probs, targets = ctx.saved_tensors
+        dp = torch.empty_like(probs)
+        _hip.check(_hip.lib().ocean_bce_elem_bwd(_hip.dev_ptr(probs), _hip.dev_ptr(targets), _hip.dev_ptr(dout.contiguous().float()),
+                                                 probs.numel(), _hip.dev_ptr(dp), _hip.stream()), "ocean_bce_elem_bwd")
+        return dp, None
+
+
 def binary_cross_entropy(probs: torch.Tensor, targets: torch.Tensor, reduction: str = "mean") -> torch.Tensor:
     """F.binary_cross_entropy on probabilities (ocean_model.py:249-253), log terms clamped at -100."""
     if probs.shape != targets.shape:
         raise ValueError(f"Using a target size ({tuple(targets.shape)}) that is different to the input size "
                          f"({tuple(probs.shape)}) is deprecated. Please ensure they have the same size.")
+    if reduction == "none":
+        return _BceElem.apply(probs.contiguous().float(), targets.to(probs.device).contiguous().float())
     if reduction not in ("mean", "sum"):
-        raise NotImplementedError("reduction must be 'mean' or 'sum'")
+        raise ValueError(f"{reduction} is not a valid value for reduction")
     loss = _Bce.apply(probs.contiguous().float(), targets.to(probs.device).contiguous().float(),
                       0 if reduction == "mean" else 1)
     return loss
