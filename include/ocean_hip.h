@@ -13,7 +13,8 @@
  *    buffer (outputs and workspaces included) and the work is enqueued on
  *    `stream` (a hipStream_t passed as void*; NULL = the default stream);
  *  - return value: 0 on success, else an OceanStatus code (1 bad shape,
- *    2 unsupported size, 3 workspace too small, 4 null pointer,
+ *    2 unsupported size, 3 workspace too small, 4 null pointer, 5 beyond the
+ *    built-in scratch array (ocean_infonce_fwd_static only),
  *    1000 + hipError_t for a launch failure);
  *  - gradient outputs named d<param> are ACCUMULATED into (+=); activation
  *    gradients are overwritten unless stated.
@@ -241,6 +242,19 @@ int ocean_infonce_rows_fwd(const ocean_infonce_shape* s, const float* anchor, co
 int ocean_infonce_rows_bwd(const ocean_infonce_shape* s, const float* anchor, const float* positive, float* ws, float* ws_bwd,
                            size_t ws_bwd_floats, const float* d_row_loss /* [B] */, float* d_anchor, float* d_positive,
                            void* stream);
+
+/* ocean_infonce_fwd for callers that cannot allocate device memory (code under HIP-graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): the same computation and result, with the workspace taken from an array
+ * built into the library instead of a caller-provided buffer.  No counterpart in the reference.  Neither this call nor
+ * anything it uses allocates or frees.  Limits and sharing:
+ *  - ocean_infonce_workspace(s) must not exceed OCEAN_STATIC_SCRATCH_FLOATS (e.g. B = Bp = 1024, P = 128 in-batch needs
+ *    1.32 M floats and fits); larger problems are refused with status 5 (use ocean_infonce_fwd);
+ *  - each GPU holds one copy of the array (6 MB) from the library's load to the end of the process, shared by every call
+ *    on that GPU: calls that overlap on one GPU (two streams, two threads) race on it - serialise them;
+ *  - the backward pass needs the state the forward leaves in its workspace, so this variant is forward-only. */
+#define OCEAN_STATIC_SCRATCH_FLOATS (1536 * 1024)
+int ocean_infonce_fwd_static(const ocean_infonce_shape* s, const float* anchor, const float* positive, const float* negatives,
+                             float* loss /* ACCUMULATED, as in ocean_infonce_fwd */, void* stream);
 
 /* The three in-batch pairs of ContrastiveLearningModule.forward in one call (graph_fusion.py:231-249 builds the pairs
  * (temporal, spatial), (temporal, log), (spatial, log) and calls InfoNCELoss.forward, :112-162, on each).

@@ -11,6 +11,7 @@ enum OceanStatus {
   OCEAN_ERR_UNSUPPORTED = 2,    // a size beyond a kernel's compiled limit
   OCEAN_ERR_WORKSPACE = 3,      // caller workspace too small
   OCEAN_ERR_NULL = 4,           // required pointer is null
+  OCEAN_ERR_SCRATCH = 5,        // the problem needs more than the library's built-in scratch array holds
   OCEAN_ERR_HIP = 1000          // + hipError_t
 };
 

@@ -308,6 +308,49 @@ int ocean_infonce_rows_bwd(const ocean_infonce_shape* s, const float* anchor, co
   return infonce_bwd_impl(s, anchor, positive, ws, wb, wb_floats, d_row_loss, 1, d_anchor, d_positive, stream);
 }
 
+// ---------------------------------------------------------------- InfoNCE forward for callers that cannot allocate
+// The workspace of ocean_infonce_fwd (normalised copies, the similarity matrix, row norms and log-sum-exps) lives in
+// one array that is part of the code object, so no allocation happens at any time: not here, not in the caller.
+// Every GPU the library runs on holds its own copy of the array (OCEAN_STATIC_SCRATCH_FLOATS * 4 bytes = 6 MB) until
+// the process ends.  In host code the array's name is only a handle for hipGetSymbolAddress: the device address is
+// looked up once per device, with that device current, and every launch gets that address as an ordinary argument.
+static __device__ __align__(256) float scratch[OCEAN_STATIC_SCRATCH_FLOATS];
+
+static constexpr int kMaxDevices = 64;
+static float* g_scratch_ptr[kMaxDevices];          // per device: address of that device's copy of `scratch`
+static bool g_scratch_known[kMaxDevices];
+
+// the current device's copy of `scratch`; 0 on success
+static int static_scratch(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return OCEAN_ERR_HIP + (int)e;
+  if (dev < 0 || dev >= kMaxDevices) return OCEAN_ERR_UNSUPPORTED;
+  // two threads of one process may both look the address up the first time; they store the same value
+  if (!__atomic_load_n(&g_scratch_known[dev], __ATOMIC_ACQUIRE)) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return OCEAN_ERR_HIP + (int)e;
+    if (p == nullptr) return OCEAN_ERR_NULL;
+    g_scratch_ptr[dev] = static_cast<float*>(p);
+    __atomic_store_n(&g_scratch_known[dev], true, __ATOMIC_RELEASE);
+  }
+  *out = g_scratch_ptr[dev];
+  return OCEAN_OK;
+}
+
+int ocean_infonce_fwd_static(const ocean_infonce_shape* s, const float* anchor, const float* positive, const float* negatives,
+                             float* loss, void* stream) {
+  NcePlan pl;
+  OCEAN_TRY(nce_plan(s, &pl));
+  if (pl.total > (size_t)OCEAN_STATIC_SCRATCH_FLOATS) return OCEAN_ERR_SCRATCH;     // beyond the built-in array: use ocean_infonce_fwd
+  float* ws = nullptr;
+  OCEAN_TRY(static_scratch(&ws));
+  // Nothing in the workspace is accumulated into: the normalised rows, the norms, the similarity matrix and the
+  // log-sum-exps are all overwritten before they are read, so the previous call's contents need no clearing.
+  return infonce_fwd_impl(s, anchor, positive, negatives, ws, pl.total, loss, nullptr, stream);
+}
+
 // ---------------------------------------------------------------- the three in-batch pairs at once
 // Z [3, B, P]: the three modality projections.  Pair q of {(0,1), (0,2), (1,2)} takes rows of Z[a] as anchors and rows
 // of the positives' [b] as positives; the positives are Z itself, or (data parallel) G [3, Bp, P] = Z gathered from

@@ -18,7 +18,8 @@ MAX_CONV_LAYERS = 8
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libocean_hip.so")
 _lib = None
 
-_STATUS = {1: "bad shape", 2: "unsupported size", 3: "workspace too small", 4: "null pointer"}
+_STATUS = {1: "bad shape", 2: "unsupported size", 3: "workspace too small", 4: "null pointer",
+           5: "the problem exceeds the library's built-in scratch array"}
 
 
 class OceanHipError(RuntimeError):
@@ -138,6 +139,7 @@ def _declare_rest(lib) -> None:
     sig("ocean_diversity_workspace", c_size_t, c_int, c_int)
     sig("ocean_diversity_fwd", c_int, vp, c_int, c_int, vp, c_size_t, vp, vp)
     sig("ocean_diversity_bwd", c_int, c_int, c_int, vp, vp, vp, vp)
+    sig("ocean_infonce_fwd_static", c_int, ip, vp, vp, vp, vp, vp)
     sig("ocean_infonce_rows_fwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp)
     sig("ocean_infonce_rows_bwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp, vp, vp)
     sig("ocean_bce_elem_fwd", c_int, vp, vp, c_long, vp, vp)
