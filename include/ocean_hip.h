@@ -276,6 +276,13 @@ int ocean_infonce3_bwd(const ocean_infonce3_shape* s, float* ws, float* ws_bwd, 
                        const float* dlosses /* device [3] or NULL (= 1, 1, 1) */, float* dZ /* [3, B, P] */,
                        float* dG /* [3, Bp, P]; NULL iff Bp == 0 */, void* stream);
 
+/* ContrastiveLearningModule._update_memory_bank (graph_fusion.py:251-273) as a ring, pointer on the device: rows [R, P]
+ * go to bank[(ptr + r) % K] (bank [K, P]; of more than K rows the last K survive), then *ptr (int64, the module's
+ * memory_ptr buffer) advances by the reference's formula: (ptr+R) % K while ptr+R <= K, ptr+R-K while <= 2K (which
+ * yields K itself at ptr+R == 2K, as the reference stores it), (ptr+R) % K beyond (where the reference raises).
+ * Keeping the pointer off the host lets the write sit in a captured HIP graph. */
+int ocean_bank_ring_write(float* bank, long long* ptr, const float* rows, int R, int K, int P, void* stream);
+
 /* MINE estimates of GraphFusionModule._compute_mutual_information (graph_fusion.py:475-501) for the three modalities:
  * mi[m] = mean_b f(cat(fused_b, X_{b,m})) - log(mean_b exp f(cat(fused_b, X_{perms[m][b],m})) + 1e-8),
  * f = Linear(E -> 1)(ReLU(Linear(2E -> E)(.))) with weights w0 [E, 2E], b0 [E], w1 [E], b1 [1].

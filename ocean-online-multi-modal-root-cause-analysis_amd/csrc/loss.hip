@@ -308,6 +308,42 @@ int ocean_infonce_rows_bwd(const ocean_infonce_shape* s, const float* anchor, co
   return infonce_bwd_impl(s, anchor, positive, ws, wb, wb_floats, d_row_loss, 1, d_anchor, d_positive, stream);
 }
 
+// ---------------------------------------------------------------- memory-bank ring
+// ContrastiveLearningModule._update_memory_bank (graph_fusion.py:251-273) with the write pointer kept on the device:
+// rows [R, P] are written at bank[(ptr + r) % K] (when R > K only the last K rows survive a full lap), then the
+// pointer advances by the reference's formula, which leaves the out-of-range value K when ptr + R == 2K.  Two
+// launches: every block of the first reads the pointer, so it may only change afterwards.
+namespace {
+__global__ void bank_ring_write_kernel(float* __restrict__ bank, const long long* __restrict__ ptr, const float* __restrict__ rows,
+                                       int R, int K, int P) {
+  const long long p0 = ptr[0];
+  const int skip = R > K ? R - K : 0;                  // rows a later row of this same call would overwrite
+  const long n = (long)(R - skip) * P;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / P) + skip, c = (int)(i % P);
+    const int dst = (int)(((p0 + r) % K + K) % K);
+    bank[(long)dst * P + c] = rows[(long)r * P + c];
+  }
+}
+__global__ void bank_ring_advance_kernel(long long* __restrict__ ptr, int R, int K) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long p0 = ptr[0], e = p0 + R;
+    ptr[0] = (e <= K) ? e % K : (e <= 2LL * K ? e - K : e % K);
+  }
+}
+}  // namespace
+
+int ocean_bank_ring_write(float* bank, long long* ptr, const float* rows, int R, int K, int P, void* stream) {
+  if (!bank || !ptr || !rows) return OCEAN_ERR_NULL;
+  if (R <= 0 || K <= 0 || P <= 0) return OCEAN_ERR_BAD_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bank_ring_write_kernel, dim3(egrid((long)(R > K ? K : R) * P)), dim3(256), 0, st, bank, ptr, rows, R, K, P);
+  OCEAN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bank_ring_advance_kernel, dim3(1), dim3(64), 0, st, ptr, R, K);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
 // ---------------------------------------------------------------- InfoNCE forward for callers that cannot allocate
 // The workspace of ocean_infonce_fwd (normalised copies, the similarity matrix, row norms and log-sum-exps) lives in
 // one array that is part of the code object, so no allocation happens at any time: not here, not in the caller.

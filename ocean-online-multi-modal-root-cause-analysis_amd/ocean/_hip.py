@@ -139,6 +139,7 @@ def _declare_rest(lib) -> None:
     sig("ocean_diversity_workspace", c_size_t, c_int, c_int)
     sig("ocean_diversity_fwd", c_int, vp, c_int, c_int, vp, c_size_t, vp, vp)
     sig("ocean_diversity_bwd", c_int, c_int, c_int, vp, vp, vp, vp)
+    sig("ocean_bank_ring_write", c_int, vp, vp, vp, c_int, c_int, c_int, vp)
     sig("ocean_infonce_fwd_static", c_int, ip, vp, vp, vp, vp, vp)
     sig("ocean_infonce_rows_fwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp)
     sig("ocean_infonce_rows_bwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp, vp, vp)
@@ -231,9 +232,71 @@ def new_seed(p: float) -> int:
     return int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0
 
 
+class GradArena:
+    """One persistent flat fp32 buffer holding the gradient of every parameter of a model, in parameter order (each slot
+    padded to 16 bytes).  While an arena is registered, the component drivers write their parameter gradients into its
+    slots (zero_grads_like below) instead of into a fresh allocation per backward pass, so that after backward every
+    p.grad is a view of the arena: a data-parallel caller all-reduces the arena in place (no packing into a bucket and
+    back), and the optimizer's chunk table, which holds gradient addresses, never changes.  Assumes each component
+    runs once per backward pass (a second use would zero the first one's gradients instead of adding to them)."""
+
+    def __init__(self, params):
+        params = [p for p in params]
+        if not params:
+            raise OceanHipError("GradArena needs parameters")
+        self.device = params[0].device
+        self.slots = {}
+        off = 0
+        for p in params:
+            if p.device != self.device or p.dtype != torch.float32:
+                raise OceanHipError("GradArena: parameters must be fp32 on one device")
+            self.slots[p.data_ptr()] = (off, p.numel(), tuple(p.shape))
+            off += (p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(off, device=self.device, dtype=torch.float32)
+
+    def offset_of(self, p: torch.Tensor) -> int:
+        return self.slots[p.data_ptr()][0]
+
+    def take(self, params, skip=None):
+        """Views of the slots of `params` after zeroing the span they cover (one fill), or None when a parameter is
+        not in this arena."""
+        lo, hi, found = None, 0, []
+        for i, p in enumerate(params):
+            if skip is not None and skip[i]:
+                found.append(None)
+                continue
+            slot = self.slots.get(p.data_ptr())
+            if slot is None or slot[2] != tuple(p.shape):
+                return None
+            found.append(slot)
+            lo = slot[0] if lo is None else min(lo, slot[0])
+            hi = max(hi, slot[0] + slot[1])
+        if lo is None:
+            return [None] * len(params)
+        self.flat[lo:hi].zero_()
+        return [None if sl is None else self.flat[sl[0]: sl[0] + sl[1]].view(sl[2]) for sl in found]
+
+
+_arenas: list = []
+
+
+def register_grad_arena(arena: Optional[GradArena]) -> None:
+    if arena is not None and all(a is not arena for a in _arenas):
+        _arenas.append(arena)
+
+
+def unregister_grad_arena(arena: GradArena) -> None:
+    _arenas[:] = [a for a in _arenas if a is not arena]
+
+
 def zero_grads_like(params, skip=None):
     """Zero-initialised gradient buffers for `params` as views of ONE flat allocation (one fill kernel
-    instead of one per tensor).  skip[i] True -> None for that slot."""
+    instead of one per tensor).  skip[i] True -> None for that slot.  With a registered GradArena that holds these
+    parameters the buffers are its slots."""
+    for arena in _arenas:
+        got = arena.take(params, skip)
+        if got is not None:
+            return got
     sizes = [0 if (skip is not None and skip[i]) else (p.numel() + 3) // 4 * 4 for i, p in enumerate(params)]
     total = sum(sizes)
     if total == 0:

@@ -142,6 +142,9 @@ class DilatedCNN(nn.Module):
         # statistics block, and the global number of rows behind those statistics
         self.stats_all_reduce: Optional[Callable[[torch.Tensor], None]] = None
         self.stats_world_size: int = 1
+        # optional callable(local batch) -> samples of this step summed over the ranks, for ranks whose batches differ in
+        # size (default: stats_world_size * local batch)
+        self.stats_global_rows: Optional[Callable[[int], int]] = None
 
     # ------------------------------------------------------------------ plumbing
     def _bn_modules(self):
@@ -149,6 +152,13 @@ class DilatedCNN(nn.Module):
             yield blk.batch_norm
         for tr in self.transition_layers:
             yield tr[1]
+
+    def _global_batch(self, local_batch: int) -> int:
+        if self.stats_all_reduce is None:
+            return local_batch
+        if self.stats_global_rows is not None:
+            return int(self.stats_global_rows(local_batch))
+        return local_batch * self.stats_world_size
 
     def _param_list(self):
         ps = [self.input_projection.weight, self.input_projection.bias]
@@ -177,7 +187,7 @@ class DilatedCNN(nn.Module):
         s.training = int(self.training)
         bn0 = self.conv_layers[0].batch_norm
         s.eps, s.momentum = bn0.eps, (bn0.momentum if bn0.momentum is not None else 0.1)
-        s.bn_count = x.shape[0] * x.shape[1] * (self.stats_world_size if self.stats_all_reduce else 1)
+        s.bn_count = x.shape[1] * self._global_batch(x.shape[0])
         p = self.conv_layers[0].dropout.p if self.training else 0.0
         s.dropout = p
         s.seed = _hip.new_seed(p)
@@ -201,7 +211,7 @@ class DilatedCNN(nn.Module):
                 or any(not b.use_residual for b in self.conv_layers):
             raise NotImplementedError("the HIP path implements relu activation, mean pooling, odd kernel sizes")
         bsz, seq = x.shape[0], x.shape[1]
-        if self.training and bsz * seq * (self.stats_world_size if self.stats_all_reduce else 1) == 1:
+        if self.training and seq * self._global_batch(bsz) == 1:
             raise ValueError(f"Expected more than 1 value per channel when training, got input size "
                              f"{torch.Size([bsz, self.channels[0], seq])}")
         x = x.contiguous().float()

@@ -77,12 +77,11 @@ class ContrastiveLearningModule(nn.Module):
         # data-parallel hooks (in-batch negatives): gather [B_loc,P] -> [B_glob,P] keeping autograd, and this rank's row offset
         self.gather_positives: Optional[Callable[[torch.Tensor], torch.Tensor]] = None
         self.rank_row_offset: Callable[[int], int] = lambda local_rows: 0
-        self._ptr_host: Optional[int] = None       # host shadow of memory_ptr (avoids a device read per step)
+        # data-parallel hook (memory-bank negatives): [M, B_loc, P] -> [M, B_all, P], the projections of every rank in
+        # rank order, so that each rank writes the whole batch's rows into its copy of the ring and the copies stay equal
+        self.gather_bank_rows: Optional[Callable[[torch.Tensor], torch.Tensor]] = None
+        self.device_ring = True                    # the ring pointer lives in memory_ptr on the device (capturable)
         self.batch_pairs = os.environ.get("OCEAN_INFONCE_PER_PAIR") != "1"     # measurement switch: one call per pair
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        super()._load_from_state_dict(*args, **kwargs)
-        self._ptr_host = None
 
     def _get_negatives(self) -> torch.Tensor:
         return self.memory_bank.clone().detach()
@@ -124,30 +123,26 @@ class ContrastiveLearningModule(nn.Module):
                                                                   label_offset=self.rank_row_offset(pa.shape[0]))
         return losses
 
-    def _update_memory_bank(self, projections: Dict[str, torch.Tensor]) -> None:
-        """Ring write of cat(projections) at memory_ptr.  Contents equal the
-        reference's on every step it survives; the stored pointer follows its
-        formula (including the out-of-range value K when ptr + R == 2K)."""
+    def _update_memory_bank(self, projections, stacked: Optional[torch.Tensor] = None) -> None:
+        """Ring write of cat(projections) at memory_ptr.  Contents equal the reference's on every step it survives; the
+        stored pointer follows its formula (including the out-of-range value K when ptr + R == 2K).  `stacked`
+        [M, B, P] holds the same projections in dictionary order (as the fused driver produces them): no concatenation.
+        Data parallel: the rows of all ranks are gathered first, so every rank performs the identical write."""
         if not projections:
             return
-        rows = torch.cat([p.detach() for p in projections.values()], dim=0)
-        K, R = self.num_negatives, rows.shape[0]
-        if self._ptr_host is None:
-            self._ptr_host = int(self.memory_ptr.item())
-        ptr = self._ptr_host
-        start = ptr
-        if R > K:                                   # only the last K rows survive a full lap
-            rows, start = rows[R - K:], (ptr + R - K) % K
-        idx = (start + torch.arange(rows.shape[0], device=rows.device)) % K
-        self.memory_bank.index_copy_(0, idx, rows.to(self.memory_bank.dtype))
-        if ptr + R <= K:
-            new_ptr = (ptr + R) % K
-        elif ptr + R <= 2 * K:
-            new_ptr = ptr + R - K
-        else:
-            new_ptr = (ptr + R) % K
-        self._ptr_host = new_ptr
-        self.memory_ptr.fill_(new_ptr)
+        if stacked is None:
+            stacked = torch.stack([p.detach() for p in projections.values()], dim=0)
+        stacked = stacked.detach()
+        if self.gather_bank_rows is not None:
+            stacked = self.gather_bank_rows(stacked)
+        rows = stacked.reshape(-1, stacked.shape[-1]).to(self.memory_bank.dtype).contiguous()
+        K, P = self.memory_bank.shape
+        if rows.shape[1] != P:
+            raise ValueError(f"projection width {rows.shape[1]} does not match the memory bank's {P}")
+        _hip.check(_hip.lib().ocean_bank_ring_write(_hip.dev_ptr(self.memory_bank, "memory_bank"),
+                                                    _hip.dev_ptr(self.memory_ptr, "memory_ptr", torch.int64),
+                                                    _hip.dev_ptr(rows, "rows"), rows.shape[0], K, P, _hip.stream()),
+                   "ocean_bank_ring_write")
 
     def forward(self, modality_features, return_projections: bool = False):
         raise NotImplementedError("projections are produced by GraphFusionModule's fused driver; "
@@ -264,7 +259,7 @@ class GraphFusionModule(nn.Module):
             projections = {"temporal": Zp[0], "spatial": Zp[1], "log": Zp[2]}
             results["contrastive_losses"] = cm.losses_from_projections(projections, stacked=Zp)
             if cm.training and cm.negatives == "bank":
-                cm._update_memory_bank(projections)
+                cm._update_memory_bank(projections, stacked=Zp)
             results["projections"] = projections
             results["mutual_information"] = self._mutual_information(fused, X) if self.compute_mutual_information else {}
         return results

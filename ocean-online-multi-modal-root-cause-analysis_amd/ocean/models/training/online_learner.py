@@ -167,6 +167,8 @@ class _GraphedStep:
             outputs = model(self.metrics, service_graph, self.logs)
             losses = model.compute_loss(outputs, self.labels)
             losses["total_loss"].backward()
+            if learner.grad_sync is not None:
+                learner.grad_sync(model)               # RCCL collectives: recorded as nodes of the graph
             opt.step(max_norm=clip if clip > 0 else 0.0)
             self.keys = [k for k in ("total_loss", "prediction_loss", "contrastive_loss") if torch.is_tensor(losses.get(k))]
             self.loss_vec = torch.stack([losses[k].detach().float().reshape(()) for k in self.keys])
@@ -205,8 +207,11 @@ class OnlineLearner:
         self.data_queue: queue.Queue = queue.Queue(maxsize=1000)
         self.is_streaming = False
         self.stream_thread: Optional[threading.Thread] = None
-        # data-parallel hook: called with the list of parameters after backward, before the update
+        # data-parallel hooks (ocean.parallel.DataParallel sets both): grad_sync(model) runs after backward and before
+        # the update; data_parallel knows whether its collectives can sit in a recorded step and how to weight a step in
+        # which the ranks hold different numbers of rows
         self.grad_sync = None
+        self.data_parallel = None
         # use_hip_graph: after two eager steps with the same batch shape and graph, process_tensors records the
         # step as a HIP graph and replays it from then on (single-GPU, FusedAdam, in-batch contrastive mode)
         self.use_hip_graph = False
@@ -249,9 +254,16 @@ class OnlineLearner:
             self._mods = list(self.model.modules())
         return self._mods
 
+    def _weighted(self, total_loss: torch.Tensor) -> torch.Tensor:
+        """Data parallel with unequal batches per rank: the local mean loss times world * local rows / global rows, so
+        that the rank-averaged gradient is that of the mean over all rows (1 for equal batches)."""
+        dp = self.data_parallel
+        w = 1.0 if dp is None else dp.loss_weight()
+        return total_loss if w == 1.0 else total_loss * w
+
     def _apply_update(self, total_loss: torch.Tensor) -> None:
         self.optimizer.zero_grad()
-        total_loss.backward()
+        self._weighted(total_loss).backward()
         if self.grad_sync is not None:
             self.grad_sync(self.model)
         clip = self.config.training.gradient_clip_norm
@@ -265,11 +277,16 @@ class OnlineLearner:
 
     def process_sample(self, sample: DatasetSample, update_model: bool = True) -> Dict[str, float]:
         self._train_mode()
-        outputs = self.model(sample.metrics.unsqueeze(0), sample.graph, sample.logs.unsqueeze(0))
-        losses = self.model.compute_loss(outputs, sample.label.unsqueeze(0))
-        if update_model:
-            self._apply_update(losses["total_loss"])
-        host = self._losses_to_host(losses)
+        metrics, logs, label = sample.metrics.unsqueeze(0), sample.logs.unsqueeze(0), sample.label.unsqueeze(0)
+        # the per-sample update is the latency-critical path of the streaming worker: with use_hip_graph it is one
+        # graph launch, like the batch update
+        host = self._graph_step(metrics, sample.graph, logs, label) if (update_model and self.use_hip_graph) else None
+        if host is None:
+            outputs = self.model(metrics, sample.graph, logs)
+            losses = self.model.compute_loss(outputs, label.to(self.model.device, non_blocking=True))
+            if update_model:
+                self._apply_update(losses["total_loss"])
+            host = self._losses_to_host(losses)
         importance_score = host["total_loss"]
         self._remember(sample, importance_score)
         if update_model:
@@ -356,8 +373,10 @@ class OnlineLearner:
             return "the optimizer is not ocean.optim.FusedAdam (its step is not capturable)"
         if len(self.optimizer.param_groups) != 1:
             return "the optimizer has several parameter groups"
-        if self.grad_sync is not None and not getattr(self.grad_sync, "capturable", False):
-            return "a gradient synchronisation hook that cannot be captured is installed"
+        if self.grad_sync is not None and not getattr(self.data_parallel, "capturable", False):
+            return "the gradient synchronisation hook's collectives cannot be captured (no RCCL transport)"
+        if self.data_parallel is not None and self.data_parallel.loss_weight() != 1.0:
+            return "the ranks hold different numbers of rows in this step"
         if self.model.contrastive_negatives != "in_batch" and not getattr(
                 self.model.fusion_module.contrastive_module, "device_ring", False):
             return "memory-bank negatives with the ring pointer kept on the host"

@@ -42,6 +42,10 @@ class LossFunction(nn.Module):
         super().__init__()
         self.prediction_weight, self.contrastive_weight = prediction_weight, contrastive_weight
         self.consistency_weight, self.diversity_weight = consistency_weight, diversity_weight
+        # data-parallel hook: [B_loc, E] -> [B_all, E] keeping autograd (backward: reduce-scatter).  The diversity term
+        # couples every pair of rows of the batch (trainer.py:97-110), so N ranks evaluate it on the gathered rows; the
+        # other terms are means over rows and need no exchange
+        self.gather_rows = None
 
     def forward(self, predictions: Dict[str, Any], targets: torch.Tensor, temporal_features: Optional[torch.Tensor] = None,
                 prev_temporal_features: Optional[torch.Tensor] = None) -> Dict[str, Any]:
@@ -61,7 +65,8 @@ class LossFunction(nn.Module):
         diversity: Any = 0.0
         inter = predictions.get("intermediate")
         if inter is not None and "fused_representation" in inter:
-            diversity = ops.diversity_loss(inter["fused_representation"])
+            fused = inter["fused_representation"]
+            diversity = ops.diversity_loss(fused if self.gather_rows is None else self.gather_rows(fused))
         losses["diversity_loss"] = diversity
         losses["total_loss"] = (self.prediction_weight * pred_loss + self.contrastive_weight * total_c +
                                 self.consistency_weight * consistency + self.diversity_weight * diversity)
@@ -145,7 +150,8 @@ class Trainer:
         self.training_start_time: Optional[datetime] = None
         self.online_learner = None
         self.prev_temporal_features: Optional[torch.Tensor] = None
-        self.grad_sync = None                      # data-parallel hook, see ocean.parallel
+        self.grad_sync = None                      # data-parallel hooks, see ocean.parallel.DataParallel
+        self.data_parallel = None
 
     # ------------------------------------------------------------------ one batch
     def _move_batch_to_device(self, batch: Dict[str, Any]) -> Dict[str, Any]:

@@ -1,17 +1,26 @@
 """Data-parallel execution of the online step: one process per GPU, RCCL over xGMI.
 
 The reference has no distributed code; this is the MI355X scaling path.  The
-model shards over samples; three quantities couple the ranks and each is one
-collective on torch.distributed's default backend ("nccl" == RCCL on ROCm,
-"gloo" in CPU tests):
+model shards over samples; these quantities couple the ranks, each through one
+collective of torch.distributed's backend ("nccl" == RCCL on ROCm; "gloo" in
+CPU tests and in one-GPU rehearsals):
 
-* gradients: one all-reduce of a single flat fp32 bucket per step, averaged;
+* gradients: every p.grad is a view of one flat arena (ocean._hip.GradArena),
+  which is all-reduced in place (average) - the attention / fusion / head part
+  as soon as backward reaches the encoders, the encoders' part at the end;
 * training-mode BatchNorm statistics of the dilated CNN: an all-reduce of each
   layer's fp64 [sum, sum of squares] block (forward) and [sum g, sum g*xhat]
   block (backward), so N ranks reproduce the single-process global-batch
   statistics;
-* InfoNCE in-batch negatives: an all-gather of the positive projections whose
-  backward is a reduce-scatter.
+* InfoNCE in-batch negatives: an all-gather of the projections whose backward
+  is a reduce-scatter; memory-bank negatives: an all-gather of the rows every
+  rank then writes into its (identical) copy of the ring;
+* the Trainer's feature-diversity term: an all-gather of the fused rows.
+
+Ranks may hold different numbers of rows in one step (sharded streams): the
+learner tells DataParallel the local and the global row count of the step and
+the losses and BatchNorm counts are weighted accordingly; a rank without data
+takes part with weight 0.
 """
 from __future__ import annotations
 
@@ -21,59 +30,137 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from . import _hip
 
+
+# ---------------------------------------------------------------------------------------------- transports
+class Transport:
+    """The collectives the data-parallel step needs, on device tensors through torch.distributed (RCCL when the
+    group's backend is "nccl").  `capturable`: the calls may be recorded into a HIP graph."""
+
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.backend = dist.get_backend(group)
+        self.capturable = self.backend == "nccl"
+
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> None:
+        dist.broadcast(t, src=src, group=self.group)
+
+    def all_reduce(self, t: torch.Tensor, op: str = "sum", async_op: bool = False):
+        """In place; op in {'sum', 'avg', 'max'}.  Returns a handle with wait() when async_op."""
+        if op == "avg" and self.backend != "nccl":            # gloo has no averaging reduction
+            w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                return _ThenScale(w, t, 1.0 / self.world)
+            t.div_(self.world)
+            return None
+        rop = {"sum": dist.ReduceOp.SUM, "avg": dist.ReduceOp.AVG, "max": dist.ReduceOp.MAX}[op]
+        return dist.all_reduce(t, op=rop, group=self.group, async_op=async_op)
+
+    def all_gather(self, out: torch.Tensor, x: torch.Tensor) -> None:
+        dist.all_gather_into_tensor(out, x.contiguous(), group=self.group)
+
+    def reduce_scatter(self, out: torch.Tensor, x: torch.Tensor) -> None:
+        if self.backend == "gloo":                            # gloo has no reduce_scatter: all-reduce, then slice
+            x = x.contiguous().clone()
+            dist.all_reduce(x, group=self.group)
+            out.copy_(x[self.rank * out.shape[0]:(self.rank + 1) * out.shape[0]])
+        else:
+            dist.reduce_scatter_tensor(out, x.contiguous(), group=self.group)
+
+    def barrier(self) -> None:
+        dist.barrier(group=self.group)
+
+
+class _ThenScale:
+    def __init__(self, work, t, f):
+        self.work, self.t, self.f = work, t, f
+
+    def wait(self):
+        self.work.wait()
+        self.t.mul_(self.f)
+        return True
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+class HostStagedTransport(Transport):
+    """The same collectives with every message staged through host memory and sent over gloo: for ranks that SHARE
+    one GPU (two RCCL ranks cannot), i.e. rehearsals and tests of the N > 1 control flow on a one-GPU box.  Every call
+    synchronises with the device; not capturable; its speed means nothing."""
+
+    def __init__(self, group=None):
+        super().__init__(group)
+        self.capturable = False
+
+    def broadcast(self, t, src=0):
+        c = t.detach().cpu()
+        dist.broadcast(c, src=src, group=self.group)
+        t.detach().copy_(c)
+
+    def all_reduce(self, t, op="sum", async_op=False):
+        c = t.detach().cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.group)
+        if op == "avg":
+            c /= self.world
+        t.detach().copy_(c)
+        return _Done() if async_op else None
+
+    def all_gather(self, out, x):
+        c = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(c, x.detach().cpu().contiguous(), group=self.group)
+        out.copy_(c)
+
+    def reduce_scatter(self, out, x):
+        c = x.detach().cpu().contiguous()
+        dist.all_reduce(c, group=self.group)
+        out.copy_(c[self.rank * out.shape[0]:(self.rank + 1) * out.shape[0]])
+
+
+# ---------------------------------------------------------------------------------------------- autograd collectives
 class _AllGatherRows(torch.autograd.Function):
-    """[B_loc, P] on every rank -> [world * B_loc, P]; backward: reduce-scatter(sum)."""
+    """[B_loc, ...] on every rank -> [world * B_loc, ...]; backward: reduce-scatter(sum)."""
 
     @staticmethod
-    def forward(ctx, x, group):
-        ctx.group = group
-        world = dist.get_world_size(group)
-        out = torch.empty(world * x.shape[0], *x.shape[1:], device=x.device, dtype=x.dtype)
-        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    def forward(ctx, x, transport):
+        ctx.transport = transport
+        out = torch.empty(transport.world * x.shape[0], *x.shape[1:], device=x.device, dtype=x.dtype)
+        transport.all_gather(out, x)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        world = dist.get_world_size(ctx.group)
-        g = g.contiguous()
-        out = torch.empty(g.shape[0] // world, *g.shape[1:], device=g.device, dtype=g.dtype)
-        if dist.get_backend(ctx.group) == "gloo":        # gloo has no reduce_scatter: all-reduce then slice
-            dist.all_reduce(g, group=ctx.group)
-            r = dist.get_rank(ctx.group)
-            out.copy_(g[r * out.shape[0]:(r + 1) * out.shape[0]])
-        else:
-            dist.reduce_scatter_tensor(out, g, group=ctx.group)
+        t = ctx.transport
+        out = torch.empty(g.shape[0] // t.world, *g.shape[1:], device=g.device, dtype=g.dtype)
+        t.reduce_scatter(out, g.contiguous())
         return out, None
 
 
-def all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
-    return _AllGatherRows.apply(x, group)
+def all_gather_rows(x: torch.Tensor, group_or_transport=None) -> torch.Tensor:
+    t = group_or_transport if isinstance(group_or_transport, Transport) else Transport(group_or_transport)
+    return _AllGatherRows.apply(x, t)
 
 
 class GradBucket:
-    """Flat fp32 bucket over the gradients that exist after backward: pack, one
-    all-reduce, average, unpack.  The bucket is reused across steps."""
+    """Flat fp32 bucket over a list of gradient tensors: pack, one all-reduce, average, unpack.  Used for gradients that
+    do not live in an arena (a model driven without OnlineLearner / Trainer); the bucket is reused across steps."""
 
-    def __init__(self, group=None):
-        self.group = group
+    def __init__(self, group_or_transport=None):
+        self.transport = group_or_transport if isinstance(group_or_transport, Transport) else None
+        self._group = None if isinstance(group_or_transport, Transport) else group_or_transport
         self._flat: Optional[torch.Tensor] = None
 
-    def start(self, grads: List[torch.Tensor]):
-        """Pack and launch the all-reduce without waiting for it; finish() averages and unpacks.  The collective runs
-        on the backend's own stream, ordered after the packing copies, so kernels queued afterwards overlap it."""
-        self._views = self._pack(grads)
-        self._grads = grads
-        self._work = dist.all_reduce(self._flat, group=self.group, async_op=True) if grads else None
-
-    def finish(self) -> None:
-        if getattr(self, "_work", None) is not None:
-            self._work.wait()                     # the current stream waits for the collective
-            self._flat.div_(dist.get_world_size(self.group))
-            torch._foreach_copy_(self._grads, self._views)
-        self._work = self._grads = self._views = None
-
-    def _pack(self, grads: List[torch.Tensor]) -> List[torch.Tensor]:
+    def all_reduce_mean(self, grads: List[torch.Tensor]) -> None:
+        if not grads:
+            return
+        if self.transport is None:
+            self.transport = Transport(self._group)
         n = sum(g.numel() for g in grads)
         if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
             self._flat = torch.empty(n, device=grads[0].device, dtype=torch.float32)
@@ -82,88 +169,137 @@ class GradBucket:
             views.append(self._flat[off: off + g.numel()].view_as(g))
             off += g.numel()
         torch._foreach_copy_(views, grads)
-        return views
-
-    def all_reduce_mean(self, grads: List[torch.Tensor]) -> None:
-        if not grads:
-            return
-        n = sum(g.numel() for g in grads)
-        if self._flat is None or self._flat.numel() != n or self._flat.device != grads[0].device:
-            self._flat = torch.empty(n, device=grads[0].device, dtype=torch.float32)
-        views, off = [], 0
-        for g in grads:
-            v = self._flat[off: off + g.numel()].view_as(g)
-            views.append(v)
-            off += g.numel()
-        torch._foreach_copy_(views, grads)
-        dist.all_reduce(self._flat, group=self.group)
-        self._flat.div_(dist.get_world_size(self.group))
+        self.transport.all_reduce(self._flat, "avg")
         torch._foreach_copy_(grads, views)
 
 
+# ---------------------------------------------------------------------------------------------- the wiring
 class DataParallel:
     """Wires a (model, learner) pair for N-rank data parallelism.
 
-    After construction every rank holds identical parameters and buffers
-    (broadcast from rank 0); learner.grad_sync averages gradients; the dilated
-    CNN all-reduces its BatchNorm statistics (sync_bn) and the contrastive
-    module gathers in-batch negatives from every rank."""
+    After construction every rank holds identical parameters and buffers (broadcast from rank 0).  `learner` may be an
+    OnlineLearner or a Trainer (both call learner.grad_sync(model) between backward and the optimizer step); its loss
+    function / contrastive module / temporal encoder get the gather and statistics hooks.
 
-    def __init__(self, model, learner=None, group=None, sync_bn: bool = True, early_bucket: Optional[bool] = None):
-        if not dist.is_initialized():
-            raise RuntimeError("torch.distributed is not initialised")
+    early_bucket (default on): the gradients of the attention / fusion / head stages are complete when backward reaches
+    the temporal encoder, whose backward is most of the step; their slice of the arena is all-reduced from there,
+    asynchronously, and the encoders' slice follows at the end.  It relies on every parameter being used once per
+    backward pass (true of OCEANModel)."""
+
+    def __init__(self, model, learner=None, group=None, sync_bn: bool = True, early_bucket: Optional[bool] = None,
+                 transport: Optional[Transport] = None):
+        self.transport = transport if transport is not None else Transport(group)
         self.model, self.group = model, group
-        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.world, self.rank = self.transport.world, self.transport.rank
+        self.capturable = self.transport.capturable
         with torch.no_grad():
             for t in list(model.parameters()) + list(model.buffers()):
-                dist.broadcast(t, src=0, group=group)
-        self.bucket = GradBucket(group)
-        # early_bucket (opt-in; OCEAN_DP_EARLY_BUCKET=1): gradients of the attention / fusion / head stages are complete
-        # when backward reaches the temporal encoder, whose backward is most of the step; their all-reduce is started
-        # there and runs under it, the encoders' gradients follow at the end.  Off by default: with one rank it costs
-        # 0.15 ms of host time per step, and what it hides on N ranks has not been measured.
-        self.early_bucket = GradBucket(group)
-        self._early_ids = set()
-        self._early_started = False
+                self.transport.broadcast(t, 0)
+        self.bucket = GradBucket(self.transport)
+        self.arena: Optional[_hip.GradArena] = None
+        self._split = 0
+        self._early_work = None
         if early_bucket is None:
-            early_bucket = os.environ.get("OCEAN_DP_EARLY_BUCKET") == "1"
-        if learner is not None and early_bucket:
-            late = {id(p) for enc in (model.temporal_encoder, model.spatial_encoder) for p in enc.parameters()}
-            self._early_ids = {id(p) for p in model.parameters() if id(p) not in late}
-            model.temporal_encoder.register_forward_hook(self._watch_encoder_output)
-        if sync_bn:
-            enc = model.temporal_encoder
-            enc.stats_all_reduce = lambda t: dist.all_reduce(t, group=group)
+            early_bucket = os.environ.get("OCEAN_DP_EARLY_BUCKET", "1") != "0"
+        self.early_bucket = bool(early_bucket)
+        # rows of this step: local, and summed over ranks (None: every rank holds the same number of rows)
+        self._rows_local: Optional[int] = None
+        self._rows_global: Optional[int] = None
+        params = [p for p in model.parameters() if p.requires_grad]
+        if params and params[0].is_cuda:
+            # arena order: the two encoders first, everything after them last, so that either part is one slice
+            enc = getattr(model, "temporal_encoder", None), getattr(model, "spatial_encoder", None)
+            late_ids = {id(p) for e in enc if e is not None for p in e.parameters()}
+            ordered = [p for p in params if id(p) in late_ids] + [p for p in params if id(p) not in late_ids]
+            self.arena = _hip.GradArena(ordered)
+            _hip.register_grad_arena(self.arena)
+            n_late = sum((p.numel() + 3) // 4 * 4 for p in ordered if id(p) in late_ids)
+            self._split = n_late if 0 < n_late < self.arena.flat.numel() else 0
+            if self.early_bucket and self._split and getattr(model, "temporal_encoder", None) is not None:
+                model.temporal_encoder.register_forward_hook(self._watch_encoder_output)
+        enc = getattr(model, "temporal_encoder", None)
+        if sync_bn and enc is not None:
+            enc.stats_all_reduce = self._stats_all_reduce
             enc.stats_world_size = self.world
-        cm = model.fusion_module.contrastive_module
-        cm.gather_positives = lambda z: all_gather_rows(z, group)
-        cm.rank_row_offset = lambda local_rows: self.rank * local_rows
+            enc.stats_global_rows = self._global_rows
+        fm = getattr(model, "fusion_module", None)
+        if fm is not None:
+            cm = fm.contrastive_module
+            cm.gather_positives = lambda z: all_gather_rows(z, self.transport)
+            cm.rank_row_offset = lambda local_rows: self.rank * local_rows
+            cm.gather_bank_rows = self._gather_bank_rows
         if learner is not None:
             learner.grad_sync = self.sync_grads
+            learner.data_parallel = self
+            lf = getattr(learner, "loss_function", None)
+            if lf is not None:
+                lf.gather_rows = lambda x: all_gather_rows(x, self.transport)
 
+    # ------------------------------------------------------------------ ragged steps
+    def set_step_rows(self, local_rows: Optional[int], global_rows: Optional[int]) -> None:
+        """Tell the wiring how many sample rows this rank and all ranks together hold in the coming step (sharded
+        streams: the ranks' batches differ in size, a rank may have none and then runs a stand-in batch with
+        local_rows = 0).  None, None: equal batches on every rank."""
+        self._rows_local, self._rows_global = local_rows, global_rows
+
+    def loss_weight(self) -> float:
+        """Factor for this rank's (local-mean) loss so that the rank-averaged gradient is the gradient of the mean
+        over ALL rows of the step: world * local / global (1 when batches are equal)."""
+        if self._rows_global is None:
+            return 1.0
+        return self.world * float(self._rows_local) / float(max(self._rows_global, 1))
+
+    def _global_rows(self, local_rows: int) -> int:
+        return self.world * local_rows if self._rows_global is None else self._rows_global
+
+    def _stats_all_reduce(self, t: torch.Tensor) -> None:
+        if self._rows_local == 0:
+            t.zero_()                      # a stand-in batch contributes nothing to the global statistics
+        self.transport.all_reduce(t, "sum")
+
+    # ------------------------------------------------------------------ memory bank
+    def _gather_bank_rows(self, rows: torch.Tensor) -> torch.Tensor:
+        """[M, B_loc, P] projections of this rank -> [M, B_all, P] of all ranks in rank order: the rows the
+        single-process model would have written into the bank for the whole batch (graph_fusion.py:237-245), in its
+        order.  No gradient (the bank is detached)."""
+        M, B, P = rows.shape
+        out = torch.empty(self.world, M, B, P, device=rows.device, dtype=rows.dtype)
+        self.transport.all_gather(out.view(self.world * M, B, P), rows.detach().contiguous())
+        return out.permute(1, 0, 2, 3).reshape(M, self.world * B, P)
+
+    # ------------------------------------------------------------------ gradients
     def _watch_encoder_output(self, module, inputs, output):
         if torch.is_tensor(output) and output.requires_grad and torch.is_grad_enabled():
-            output.register_hook(self._start_early_bucket)
+            output.register_hook(self._start_early_slice)
 
-    def _start_early_bucket(self, grad):
+    def _start_early_slice(self, grad):
         """Runs inside backward, when the gradient of the temporal encoder's output is known: every stage after the
-        encoders has finished its backward (parameter gradients are accumulated before the engine moves on)."""
-        if not self._early_started:
-            grads = [p.grad for p in self.model.parameters() if id(p) in self._early_ids and p.grad is not None]
-            if grads:
-                self.early_bucket.start(grads)
-                self._early_started = True
-                self._early_set = {id(g) for g in grads}
+        encoders has finished its backward, i.e. has written its parameter gradients into the arena."""
+        if self._early_work is None and self.arena is not None and self._split:
+            self._early_work = self.transport.all_reduce(self.arena.flat[self._split:], "avg", async_op=True)
         return None
 
     def sync_grads(self, model=None) -> None:
         model = model or self.model
-        # every rank must contribute the same tensors: parameters without a gradient on this rank
-        # (none on the OCEAN path) would desynchronise the bucket, so the set is taken by name order
         grads = [p.grad for p in model.parameters() if p.grad is not None]
-        if self._early_started:
-            self.bucket.all_reduce_mean([g for g in grads if id(g) not in self._early_set])
-            self.early_bucket.finish()
-            self._early_started = False
-        else:
+        if not grads:
+            return
+        a = self.arena
+        in_arena = False
+        if a is not None:
+            lo = a.flat.data_ptr()
+            hi = lo + 4 * a.flat.numel()
+            in_arena = all(lo <= g.data_ptr() < hi for g in grads)
+        if not in_arena:
+            # gradients that were not written into the arena (another driver produced them): bucket them
+            if self._early_work is not None:
+                self._early_work.wait()
+                self._early_work = None
             self.bucket.all_reduce_mean(grads)
+            return
+        if self._early_work is not None:
+            self.transport.all_reduce(a.flat[:self._split], "avg")
+            self._early_work.wait()
+            self._early_work = None
+        else:
+            self.transport.all_reduce(a.flat, "avg")

@@ -245,3 +245,66 @@ def test_replayed_steps_leave_a_frozen_components_step_count_alone():
     frozen = m.prediction_head[0].weight
     live = m.fusion_module.output_projection[0].weight
     assert int(st[frozen]["step"]) == 2 and int(st[live]["step"]) == 8
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 6, 8, 10])
+def test_memory_bank_ring_matches_reference_then_keeps_going(golden, B):
+    """ContrastiveLearningModule._update_memory_bank with the pointer on the device (ocean_bank_ring_write) against the
+    bank contents and pointer values recorded from the reference (graph_fusion.py:251-273) for every step it survives,
+    including the out-of-range pointer value 16; beyond that the ring simply continues."""
+    import numpy as np
+    from ocean.models.components import ContrastiveLearningModule
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    g = golden(f"bank_trace_B{B}")
+    cm = ContrastiveLearningModule({"temporal": 8, "spatial": 8, "log": 8}, 4, 0.1).cuda()
+    cm.memory_bank.copy_(T(g["bank0"]))
+    for st in range(len(g["ptrs"])):
+        rows = T(g["fed"][st]).cuda()
+        cm._update_memory_bank({"temporal": rows[:B], "spatial": rows[B:2 * B], "log": rows[2 * B:]})
+        assert int(cm.memory_ptr) == int(g["ptrs"][st])
+        assert torch.equal(cm.memory_bank.cpu(), T(g["banks"][st]))
+    for _ in range(6):            # where the reference raises (ptr + 3B > 32) the ring simply continues
+        cm._update_memory_bank({k: torch.randn(B, 4, device="cuda") for k in ("temporal", "spatial", "log")})
+    assert 0 <= int(cm.memory_ptr) <= 16
+    big = torch.randn(3, 11, 4, device="cuda")                                    # 33 rows > 16: the last 16 survive
+    cm._update_memory_bank({"temporal": big[0], "spatial": big[1], "log": big[2]}, stacked=big)
+    assert sorted(map(tuple, cm.memory_bank.tolist())) == sorted(map(tuple, big.reshape(33, 4)[-16:].tolist()))
+    sd = cm.state_dict()
+    sd["memory_ptr"] = torch.tensor([5])
+    cm.load_state_dict(sd)
+    cm._update_memory_bank({k: torch.randn(1, 4, device="cuda") for k in ("temporal", "spatial", "log")})
+    assert int(cm.memory_ptr) == 8
+
+
+@pytest.mark.parametrize("B", [1, 4, 7])
+def test_memory_bank_mode_replays_as_a_hip_graph(B):
+    """The reference's default contrastive mode (memory-bank negatives) and its per-sample update (B = 1,
+    online_learner.py:292-360) under use_hip_graph: the ring pointer advances on the device inside the recorded step, so
+    bank, pointer, losses and parameters follow the eagerly launched run."""
+    from datetime import datetime
+    from ocean.data import DatasetSample, ServiceGraph
+    runs = {}
+    for use_graph in (False, True):
+        cfg, m, learner = _tiny_learner(seed=13)
+        m.contrastive_negatives = "bank"
+        learner.use_hip_graph = use_graph
+        sg = ServiceGraph(synth.random_digraph(6, 2.0, 1), torch.randn(6, 7, generator=torch.Generator().manual_seed(0)))
+        cm = m.fusion_module.contrastive_module
+        trace = []
+        for s in range(7):
+            b = _tiny_batch(s, B)
+            if B == 1:
+                r = learner.process_sample(DatasetSample(b[0][0].cpu(), b[1][0].cpu(), sg, b[2][0].cpu(), datetime(2024, 1, 1)))
+                loss = r["loss"]
+            else:
+                loss = learner.process_tensors(b[0], sg, b[1], b[2])["batch_loss"]
+            trace.append((loss, int(cm.memory_ptr), cm.memory_bank.detach().clone()))
+        assert len(learner._graphed) == (1 if use_graph else 0)
+        assert learner.update_count == 7
+        runs[use_graph] = (trace, [p.detach().clone() for p in m.parameters()])
+    for (la, pa, ba), (lb, pb, bb) in zip(runs[False][0], runs[True][0]):
+        assert pa == pb
+        assert abs(la - lb) <= 1e-4 * abs(la)
+        close(bb, ba, 1e-3)
+    for a, b in zip(runs[False][1], runs[True][1]):
+        close(b, a, 3e-3)

@@ -109,13 +109,22 @@ def test_replays_draw_new_masks_and_follow_the_learning_rate():
     assert any(not torch.equal(v, before[k]) for k, v in m.named_parameters())
 
 
-def test_bank_mode_and_new_shapes_fall_back_to_eager():
+def test_ineligible_steps_run_eagerly_and_say_so_once(caplog):
+    import logging
     sg = _graph()
     m, learner = _learner(True, True, negatives="bank")
     metrics, logs, labels = _data(0, B=2)
     for _ in range(4):
         learner.process_tensors(metrics, sg, logs, labels)
-    assert len(learner._graphed) == 0          # the ring pointer of the memory bank is host state: not recorded
+    assert len(learner._graphed) == 1          # memory-bank mode is recorded too: the ring pointer lives on the device
+    # an optimizer whose step cannot be captured: the update runs as separate launches, with ONE warning that says why
+    m, learner = _learner(True, True)
+    learner.optimizer = torch.optim.Adam(m.parameters(), lr=1e-3)
+    with caplog.at_level(logging.WARNING, logger="ocean.models.training.online_learner"):
+        for _ in range(4):
+            learner.process_tensors(metrics, sg, logs, labels)
+    said = [r for r in caplog.records if "separate launches" in r.getMessage()]
+    assert len(learner._graphed) == 0 and len(said) == 1 and "FusedAdam" in said[0].getMessage()
     m, learner = _learner(True, True)
     for i in range(4):
         learner.process_tensors(*(lambda d: (d[0], sg, d[1], d[2]))(_data(i, B=3 + i)))   # a new batch size every step

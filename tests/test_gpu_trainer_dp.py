@@ -106,6 +106,8 @@ def _free_port():
 
 
 def _dp_worker(rank, world, port, fix, out):
+    """One of two ranks sharing the GPU: ocean.parallel.DataParallel itself, with the host-staged gloo transport in
+    place of RCCL (two RCCL ranks cannot share a device)."""
     import faulthandler
     import torch.distributed as dist
     faulthandler.dump_traceback_later(90, exit=True)       # a stuck rank reports where, instead of hanging the run
@@ -114,82 +116,72 @@ def _dp_worker(rank, world, port, fix, out):
     try:
         import ocean
         from ocean.data import ServiceGraph
-        from ocean.models.training import OnlineLearner
+        from ocean.models.training import OnlineLearner, Trainer
+        from ocean.parallel import DataParallel, HostStagedTransport
         cfg = tiny_config()
         m = ocean.OCEANModel(cfg)
         zero_dropout(m)
         m.load_state_dict({k: v.clone() for k, v in fix["sd"].items()})
         m = m.cuda()
-        m.contrastive_negatives = "in_batch"
-        learner = OnlineLearner(m, cfg)
-
-        # The production wiring (ocean.parallel.DataParallel) issues RCCL collectives on device tensors; one GPU
-        # cannot host two RCCL ranks, so this test installs the same three hooks with host-staged gloo collectives.
-        def all_reduce_dev(t):
-            c = t.detach().cpu()
-            dist.all_reduce(c)
-            t.copy_(c)
-
-        class GatherRows(torch.autograd.Function):
-            @staticmethod
-            def forward(ctx, x):
-                parts = [torch.zeros(x.shape) for _ in range(world)]
-                dist.all_gather(parts, x.detach().cpu())
-                return torch.cat(parts).to(x.device)
-
-            @staticmethod
-            def backward(ctx, g):
-                c = g.detach().cpu()
-                dist.all_reduce(c)
-                n = c.shape[0] // world
-                return c[rank * n:(rank + 1) * n].to(g.device)
-
-        def sync_grads(model):
-            for p in model.parameters():
-                if p.grad is not None:
-                    all_reduce_dev(p.grad)
-                    p.grad.div_(world)
-
-        enc, cm = m.temporal_encoder, m.fusion_module.contrastive_module
-        enc.stats_all_reduce, enc.stats_world_size = all_reduce_dev, world
-        cm.gather_positives, cm.rank_row_offset = GatherRows.apply, (lambda rows: rank * rows)
-        learner.grad_sync = sync_grads
+        m.contrastive_negatives = fix["negatives"]
+        if fix["trainer"]:
+            learner = Trainer(m, cfg, data_loader=None)
+        else:
+            learner = OnlineLearner(m, cfg)
+        dp = DataParallel(m, learner, transport=HostStagedTransport())
+        assert learner.grad_sync is not None and learner.data_parallel is dp and not dp.capturable
         B = fix["metrics"].shape[0] // world
         sl = slice(rank * B, (rank + 1) * B)
         sg = ServiceGraph(fix["adj"], fix["nf"])
         m.train()
-        o = m(fix["metrics"][sl], sg, fix["logs"][sl])
-        losses = m.compute_loss(o, fix["labels"][sl].cuda())
+        o = m(fix["metrics"][sl], sg, fix["logs"][sl], return_intermediate=True)
+        if fix["trainer"]:
+            losses = learner.loss_function(o, fix["labels"][sl].cuda(), o["intermediate"]["temporal_features"], None)
+        else:
+            losses = m.compute_loss(o, fix["labels"][sl].cuda())
         learner.optimizer.zero_grad()
         losses["total_loss"].backward()
         learner.grad_sync(m)
+        torch.cuda.synchronize()
+        lo, hi = dp.arena.flat.data_ptr(), dp.arena.flat.data_ptr() + 4 * dp.arena.flat.numel()
+        cm = m.fusion_module.contrastive_module
         out[rank] = {"probs": o["root_cause_probs"].detach().cpu(), "loss": float(losses["total_loss"].detach()),
                      "grads": {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None},
-                     "rm": m.temporal_encoder.conv_layers[1].batch_norm.running_mean.detach().cpu()}
+                     "in_arena": all(lo <= p.grad.data_ptr() < hi for p in m.parameters() if p.grad is not None),
+                     "rm": m.temporal_encoder.conv_layers[1].batch_norm.running_mean.detach().cpu(),
+                     "bank": cm.memory_bank.detach().cpu(), "ptr": int(cm.memory_ptr),
+                     "diversity": float(losses["diversity_loss"]) if fix["trainer"] else 0.0}
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_reproduce_single_process_full_batch():
-    import torch.multiprocessing as mp
+def _fixture(B=8):
     import ocean
     cfg = tiny_config()
-    m0 = ocean.OCEANModel(cfg)
-    sd = synth.fill_state_dict(m0.state_dict(), 21)
+    sd = synth.fill_state_dict(ocean.OCEANModel(cfg).state_dict(), 21)
     g = torch.Generator().manual_seed(5)
-    B = 8
     fix = {"sd": sd, "metrics": torch.randn(B, 12, 5, generator=g), "logs": torch.randn(B, 24, generator=g),
-           "adj": synth.random_digraph(6, 2.0, 2), "nf": torch.randn(6, 7, generator=g), "labels": torch.zeros(B, 6)}
+           "adj": synth.random_digraph(6, 2.0, 2), "nf": torch.randn(6, 7, generator=g), "labels": torch.zeros(B, 6),
+           "negatives": "in_batch", "trainer": False}
     fix["labels"][torch.arange(B), torch.randint(0, 6, (B,), generator=g)] = 1
-    # single-process full-batch oracle
-    rsd = R.require_grad(sd)
-    ro = R.model_forward(rsd, fix["metrics"], fix["adj"], fix["nf"], fix["logs"], training=True, negatives="in_batch",
+    return fix
+
+
+@pytest.mark.parametrize("negatives,trainer", [("in_batch", False), ("bank", False), ("in_batch", True)])
+def test_two_ranks_reproduce_single_process_full_batch(negatives, trainer):
+    """Two ranks on half batches, wired by DataParallel: synchronised BatchNorm statistics, gathered InfoNCE positives
+    (or, with memory-bank negatives, the gathered ring write), the Trainer's diversity term over the gathered fused
+    rows, gradients averaged in the arena - against ONE process on the full batch (the oracle)."""
+    import torch.multiprocessing as mp
+    fix = _fixture()
+    fix["negatives"], fix["trainer"] = negatives, trainer
+    rsd = R.require_grad(fix["sd"])
+    ro = R.model_forward(rsd, fix["metrics"], fix["adj"], fix["nf"], fix["logs"], training=True, negatives=negatives,
                          dilations=(1, 2), gnn_heads=2, log_dim=24)
-    rl = R.compute_loss(ro, fix["labels"])
+    rl = R.trainer_loss(ro, fix["labels"]) if trainer else R.compute_loss(ro, fix["labels"])
     rl["total_loss"].backward()
     ctx = mp.get_context("spawn")
-    mgr = ctx.Manager()
-    out = mgr.dict()
+    out = ctx.Manager().dict()
     mp.spawn(_dp_worker, args=(2, _free_port(), fix, out), nprocs=2, join=True)
     probs = torch.cat([out[0]["probs"], out[1]["probs"]])
     rel = ((probs - ro["root_cause_probs"]).abs() / ro["root_cause_probs"]).max().item()
@@ -198,7 +190,16 @@ def test_two_ranks_reproduce_single_process_full_batch():
     for k, gref in ((k, v.grad) for k, v in rsd.items() if v.grad is not None):
         for r in (0, 1):
             close(out[r]["grads"][k], gref, 1e-3)              # averaged gradients == full-batch gradients, on both ranks
+    assert out[0]["in_arena"] and out[1]["in_arena"]
     close(out[0]["rm"], rsd["temporal_encoder.conv_layers.1.batch_norm.running_mean"], 1e-5)
+    if negatives == "bank":
+        # both ranks wrote the whole batch's 3 x 8 rows, in the single-process order
+        assert out[0]["ptr"] == out[1]["ptr"] == int(rsd["fusion_module.contrastive_module.memory_ptr"])
+        assert torch.equal(out[0]["bank"], out[1]["bank"])
+        close(out[0]["bank"], rsd["fusion_module.contrastive_module.memory_bank"], 1e-4)
+    if trainer:
+        for r in (0, 1):
+            assert abs(out[r]["diversity"] - float(rl["diversity_loss"])) <= 1e-3 * abs(float(rl["diversity_loss"]))
 
 
 def _dp_class_worker(rank, world, port, fix, out):
@@ -214,52 +215,52 @@ def _dp_class_worker(rank, world, port, fix, out):
         from ocean.models.training import OnlineLearner
         from ocean.parallel import DataParallel
         cfg = tiny_config()
-        m = ocean.OCEANModel(cfg)
-        zero_dropout(m)
-        m.load_state_dict({k: v.clone() for k, v in fix["sd"].items()})
-        m = m.cuda()
-        m.contrastive_negatives = "in_batch"
-        learner = OnlineLearner(m, cfg)
-        dp = DataParallel(m, learner, early_bucket=True)
-        sg = ServiceGraph(fix["adj"], fix["nf"])
-        m.train()
         res = {}
-        for step in range(2):                      # the second pass reuses the buckets
-            o = m(fix["metrics"], sg, fix["logs"])
-            losses = m.compute_loss(o, fix["labels"].cuda())
-            learner.optimizer.zero_grad()
-            losses["total_loss"].backward()
-            started = dp._early_started
-            n_early = len(dp._early_set) if started else 0
-            before = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
-            learner.grad_sync(m)
-            torch.cuda.synchronize()
-            same = all(torch.equal(before[k], p.grad) for k, p in m.named_parameters() if p.grad is not None)
-            res[step] = {"started": bool(started), "n_early": n_early, "n_all": len(before), "same": bool(same),
-                         "reset": not dp._early_started}
-        res["grads"] = {k: v.cpu() for k, v in before.items()}
-        res["loss"] = float(losses["total_loss"].detach())
+        sg = ServiceGraph(fix["adj"], fix["nf"])
+        for mode in ("eager", "graph"):
+            m = ocean.OCEANModel(cfg)
+            zero_dropout(m)
+            m.load_state_dict({k: v.clone() for k, v in fix["sd"].items()})
+            m = m.cuda()
+            m.contrastive_negatives = "in_batch"
+            learner = OnlineLearner(m, cfg)
+            dp = DataParallel(m, learner)                  # RCCL transport, early slice on
+            assert dp.capturable and dp.early_bucket and 0 < dp._split < dp.arena.flat.numel()
+            if mode == "eager":
+                m.train()
+                o = m(fix["metrics"], sg, fix["logs"])
+                losses = m.compute_loss(o, fix["labels"].cuda())
+                learner.optimizer.zero_grad()
+                losses["total_loss"].backward()
+                started = dp._early_work is not None       # the post-encoder slice was launched from inside backward
+                before = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+                learner.grad_sync(m)
+                torch.cuda.synchronize()
+                same = all(torch.equal(before[k], p.grad) for k, p in m.named_parameters() if p.grad is not None)
+                res["eager"] = {"started": bool(started), "same": bool(same), "reset": dp._early_work is None,
+                                "grads": {k: v.cpu() for k, v in before.items()}, "loss": float(losses["total_loss"].detach())}
+            learner.use_hip_graph = mode == "graph"
+            hist = [learner.process_tensors(fix["metrics"], sg, fix["logs"], fix["labels"])["batch_loss"] for _ in range(6)]
+            res[mode + "_hist"] = hist
+            res[mode + "_params"] = [p.detach().cpu() for p in m.parameters()]
+            res[mode + "_recorded"] = len(learner._graphed)
+            from ocean import _hip
+            _hip.unregister_grad_arena(dp.arena)
         out[rank] = res
     finally:
         dist.destroy_process_group()
 
 
-def test_data_parallel_class_on_one_rccl_rank_leaves_gradients_exact():
-    """ocean.parallel.DataParallel itself (RCCL backend, one rank) with early_bucket=True: the gradient all-reduce is split into a bucket
-    started from inside backward, when the temporal encoder's output gradient arrives, and a bucket for the encoders
-    afterwards.  With one rank the average is the identity, so every gradient must come back bit-identical - which it
-    would not if the early bucket were packed before some gradient it covers was complete - and the model's gradients
-    must be those of the single-process oracle."""
+def test_data_parallel_class_on_one_rccl_rank_eager_and_recorded():
+    """ocean.parallel.DataParallel over RCCL with one rank (all a one-GPU box can host): the gradient arena is reduced
+    in two slices, the first started from inside backward; with one rank the average is the identity, so every gradient
+    must come back bit-identical - which it would not if the early slice were sent before some gradient in it was
+    complete - and equal the oracle's.  Then the whole update step INCLUDING its collectives (BatchNorm statistics,
+    gathered positives, the two gradient slices) recorded as one HIP graph and replayed: same losses and parameters as
+    the eagerly launched run."""
     import torch.multiprocessing as mp
-    import ocean
-    cfg = tiny_config()
-    sd = synth.fill_state_dict(ocean.OCEANModel(cfg).state_dict(), 21)
-    g = torch.Generator().manual_seed(5)
-    B = 8
-    fix = {"sd": sd, "metrics": torch.randn(B, 12, 5, generator=g), "logs": torch.randn(B, 24, generator=g),
-           "adj": synth.random_digraph(6, 2.0, 2), "nf": torch.randn(6, 7, generator=g), "labels": torch.zeros(B, 6)}
-    fix["labels"][torch.arange(B), torch.randint(0, 6, (B,), generator=g)] = 1
-    rsd = R.require_grad(sd)
+    fix = _fixture()
+    rsd = R.require_grad(fix["sd"])
     ro = R.model_forward(rsd, fix["metrics"], fix["adj"], fix["nf"], fix["logs"], training=True, negatives="in_batch",
                          dilations=(1, 2), gnn_heads=2, log_dim=24)
     rl = R.compute_loss(ro, fix["labels"])
@@ -268,9 +269,12 @@ def test_data_parallel_class_on_one_rccl_rank_leaves_gradients_exact():
     out = ctx.Manager().dict()
     mp.spawn(_dp_class_worker, args=(1, _free_port(), fix, out), nprocs=1, join=True)
     r = out[0]
-    for step in (0, 1):
-        assert r[step]["started"] and r[step]["same"] and r[step]["reset"], r[step]
-        assert 0 < r[step]["n_early"] < r[step]["n_all"], r[step]
-    assert abs(r["loss"] - float(rl["total_loss"])) < 1e-3 * abs(float(rl["total_loss"]))
+    assert r["eager"]["started"] and r["eager"]["same"] and r["eager"]["reset"], r["eager"]
+    assert abs(r["eager"]["loss"] - float(rl["total_loss"])) < 1e-3 * abs(float(rl["total_loss"]))
     for k, gref in ((k, v.grad) for k, v in rsd.items() if v.grad is not None):
-        close(r["grads"][k], gref, 1e-3)
+        close(r["eager"]["grads"][k], gref, 1e-3)
+    assert r["eager_recorded"] == 0 and r["graph_recorded"] == 1
+    for a, b in zip(r["eager_hist"], r["graph_hist"]):
+        assert abs(a - b) <= 1e-4 * abs(a), (r["eager_hist"], r["graph_hist"])
+    for a, b in zip(r["eager_params"], r["graph_params"]):
+        close(b, a, 3e-3)

@@ -66,31 +66,6 @@ def test_device_graph_csr_follows_gatconv_self_loop_rule():
         DeviceGraph(torch.tensor([[0], [7]]), 4, "cpu")
 
 
-@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 6, 8, 10])
-def test_memory_bank_ring_matches_reference_then_keeps_going(golden, B):
-    from ocean.models.components import ContrastiveLearningModule
-    g = golden(f"bank_trace_B{B}")
-    cm = ContrastiveLearningModule({"temporal": 8, "spatial": 8, "log": 8}, 4, 0.1)
-    cm.memory_bank.copy_(T(g["bank0"]))
-    for st in range(len(g["ptrs"])):
-        rows = T(g["fed"][st])
-        cm._update_memory_bank({"temporal": rows[:B], "spatial": rows[B:2 * B], "log": rows[2 * B:]})
-        assert int(cm.memory_ptr) == int(g["ptrs"][st])
-        assert torch.equal(cm.memory_bank, T(g["banks"][st]))
-    for _ in range(6):            # where the reference raises (ptr + 3B > 32) the ring simply continues
-        cm._update_memory_bank({k: torch.randn(B, 4) for k in ("temporal", "spatial", "log")})
-    big = {k: torch.randn(11, 4) for k in ("temporal", "spatial", "log")}      # 33 rows > 16: last 16 survive
-    cm._update_memory_bank(big)
-    allrows = torch.cat(list(big.values()))
-    assert sorted(map(tuple, cm.memory_bank.tolist())) == sorted(map(tuple, allrows[-16:].tolist()))
-    # a reloaded state_dict resynchronises the host pointer shadow
-    sd = cm.state_dict()
-    sd["memory_ptr"] = torch.tensor([5])
-    cm.load_state_dict(sd)
-    cm._update_memory_bank({k: torch.randn(1, 4) for k in ("temporal", "spatial", "log")})
-    assert int(cm.memory_ptr) == 8
-
-
 def test_adaptive_lr_scheduler_trace(golden):
     from ocean.models.training import AdaptiveLearningRateScheduler
     g = golden("lr_trace")
