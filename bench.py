@@ -7,13 +7,18 @@ forward, compute_loss (BCE + 0.1 * 3 in-batch InfoNCE), backward,
 clip_grad_norm_(1.0), Adam - what OnlineLearner.process_batch runs, including
 its one loss read-back per step.  Workload (BASELINE.json configs[2]): 256
 services (directed Erdos-Renyi graph, mean in-degree 8), seq_len 128, 12
-metric features, 768-d log embeddings, batch 1024 PER GPU (weak scaling),
-reference default hyper-parameters (dropout 0.1 everywhere, so every graph
-replica is computed), fp32.
+metric features, 768-d log embeddings, GLOBAL batch 1024 split evenly over
+the ranks (strong scaling; --weak keeps 1024 per GPU instead), reference
+default hyper-parameters (dropout 0.1 everywhere, so every graph replica is
+computed), fp32.
 
-For N > 1 launch with torch.distributed.run; ranks are data-parallel (RCCL):
-flat gradient all-reduce, all-reduced BatchNorm statistics, all-gathered
-InfoNCE positives.  Rank 0 prints ONE JSON line.
+N > 1: one process per GPU, launched by torch.distributed.run (RANK /
+LOCAL_RANK / WORLD_SIZE in the environment) or, when those are absent, by
+this script itself, which then starts N rank processes of itself before it
+touches any GPU.  Ranks are data-parallel over RCCL: gradient arena
+all-reduce, all-reduced BatchNorm statistics, all-gathered InfoNCE positives;
+the whole step, collectives included, is replayed as one HIP graph.  Rank 0
+prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -45,16 +50,33 @@ def synth_inputs(B, T, N, S, rank, device):
     return metrics.to(device), logs.to(device), nf, adj, labels.to(device)
 
 
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+LIB_FILE = os.path.join(ROOT, "ocean-online-multi-modal-root-cause-analysis_amd", "ocean", "libocean_hip.so")
+
+
+def file_sha16(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
 def recorded_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` (fetch + write), from the committed rocprofv3 --pmc passes over this
-    same command (profiles/r01_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE
-    doubled as gfx950 requires).  None when no recording matches."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    """HBM-side bytes per launch of `kernel` (fetch + write) from rocprofv3 --pmc passes over this same command
+    (tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as gfx950
+    requires).  The counters cannot be read from inside this process, so the figure comes from a recording - and only
+    from one made with the very kernel library and bench script that are running now (their hashes are stored with the
+    recording); otherwise None: a stale figure would describe other kernels."""
+    if not os.path.exists(TRAFFIC_FILE):
+        return None
+    rec = json.load(open(TRAFFIC_FILE))
+    if not isinstance(rec, dict) or rec.get("lib_sha16") != file_sha16(LIB_FILE) or rec.get("bench_sha16") != file_sha16(__file__):
         return None
     key = kernel.replace(" ", "")
     n = tot = 0.0
-    for r in json.load(open(path)):
+    for r in rec.get("kernels", []):
         if r["kernel"].replace(" ", "") == key:
             n += r["launches"]
             tot += r["launches"] * (r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"])
@@ -84,17 +106,49 @@ def cpu_baseline(model, nf, adj, T, S, budget_s=25.0):
         with torch.no_grad():
             R.adam_step([sd[k] for k in wg], [sd[k].grad for k in wg], [state[k] for k in wg])
 
-    for _ in range(2):
-        step()
-    t0 = time.perf_counter()
-    n = 0
-    while n < 10 and time.perf_counter() - t0 < budget_s:
-        step()
-        n += 1
-    dt = (time.perf_counter() - t0) / n
+    def timed(fn, budget):
+        for _ in range(3):                               # 3 warm-up + up to 10 timed iterations (evaluation/profiler.py:62-111)
+            fn()
+        t0 = time.perf_counter()
+        n = 0
+        while n < 10 and time.perf_counter() - t0 < budget:
+            fn()
+            n += 1
+        return (time.perf_counter() - t0) / n, n
+
+    dt, n = timed(step, budget_s * 0.7)
+
+    def eval_forward():
+        with torch.no_grad():
+            R.model_forward(sd, metrics, adj, nf, logs, training=False)
+
+    dte, ne = timed(eval_forward, budget_s * 0.3)
     return {"value": Bc / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} update steps of batch {Bc} (same graph, T={T}, S={S}, in-batch InfoNCE; dropout off and one graph "
-                      f"replica computed and broadcast, i.e. less work than the GPU step), {dt * 1e3:.0f} ms/step"}
+                      f"replica computed and broadcast, i.e. less work than the GPU step), {dt * 1e3:.0f} ms/step",
+            "eval_forward": {"value": Bc / dte, "unit": "samples/s",
+                             "sample": f"{ne} eval-mode forward passes of batch {Bc}, {dte * 1e3:.0f} ms each"}}
+
+
+def launch_ranks(n, argv):
+    """Start n rank processes of this script (this process has not touched a GPU and does not), wait for them and
+    return the worst exit code.  Rank 0's stdout (the JSON line) passes through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    worst = 0
+    for p in procs:
+        rc = p.wait()
+        worst = worst or rc
+    return worst
 
 
 def main():
@@ -102,61 +156,48 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=1024, help="global batch, split evenly over the ranks (per GPU with --weak)")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --batch samples on every GPU")
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--services", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (single-GPU runs replay the step as a HIP graph by default)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (by default the step is replayed as a HIP graph)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    # stdout carries the ONE JSON line and nothing else: libraries that print there (the RCCL and gloo banners) are sent
+    # to stderr by pointing descriptor 1 at it; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
-    # OCEAN_BENCH_REHEARSE=1: every rank uses GPU 0 and the collectives go through gloo, so that the N > 1 control flow
-    # (phased BatchNorm statistics, gathers, gradient bucket, barriers, max over ranks) can be run on a one-GPU box.
-    # Its numbers mean nothing: the ranks share one GPU.
+    # OCEAN_BENCH_REHEARSE=1: every rank uses GPU 0 and the collectives are staged through the host over gloo, so that
+    # the N > 1 control flow (phased BatchNorm statistics, gathers, gradient arena, barriers, max over ranks) can be
+    # run on a one-GPU box.  Its numbers mean nothing: the ranks share one GPU.
     rehearse = os.environ.get("OCEAN_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ.get("OCEAN_BENCH_REHEARSE_TIMEOUT", "90")), exit=True)   # a stuck collective names itself
+        faulthandler.dump_traceback_later(int(os.environ.get("OCEAN_BENCH_REHEARSE_TIMEOUT", "120")), exit=True)   # a stuck collective names itself
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    # OCEAN_BENCH_DIST=1 takes the data-parallel code path (RCCL process group, collectives, eager launches) with a
-    # single rank as well: a smoke test of that path on a one-GPU box
+    # OCEAN_BENCH_DIST=1 takes the data-parallel code path (RCCL process group, collectives) with a single rank as
+    # well: a smoke test of that path on a one-GPU box
     use_dist = world > 1 or os.environ.get("OCEAN_BENCH_DIST") == "1"
+    transport = None
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-            # gloo's device-tensor collectives do not complete with two processes on one GPU: stage through the host
-            _bc, _ar, _ag = dist.broadcast, dist.all_reduce, dist.all_gather_into_tensor
-
-            def _broadcast(t, src=0, group=None):
-                c = t.detach().cpu()
-                _bc(c, src=src, group=group)
-                t.detach().copy_(c)
-
-            class _Done:
-                def wait(self):
-                    return True
-
-            def _all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
-                c = t.detach().cpu()
-                _ar(c, op=op, group=group)
-                t.detach().copy_(c)
-                return _Done() if async_op else None
-
-            def _all_gather_into_tensor(out, x, group=None):
-                c = torch.empty(out.shape, dtype=out.dtype)
-                _ag(c, x.detach().cpu(), group=group)
-                out.copy_(c)
-
-            dist.broadcast, dist.all_reduce, dist.all_gather_into_tensor = _broadcast, _all_reduce, _all_gather_into_tensor
         else:
             dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
@@ -165,17 +206,22 @@ def main():
     from ocean.data import ServiceGraph
     from ocean.models.training import OnlineLearner
 
-    B, T, N = args.batch, args.seq_len, args.services
+    if args.batch % world and not args.weak:
+        raise SystemExit(f"bench.py: global batch {args.batch} is not a multiple of {world} ranks")
+    B = args.batch if args.weak else args.batch // world
+    T, N = args.seq_len, args.services
     cfg = ocean.default_config()
     cfg.model.num_services = N
     torch.manual_seed(42)
     model = ocean.OCEANModel(cfg).to(device)
     model.contrastive_negatives = "in_batch"
     learner = OnlineLearner(model, cfg)
-    learner.use_hip_graph = not use_dist and not args.no_graph
     if use_dist:
-        from ocean.parallel import DataParallel
-        DataParallel(model, learner)
+        from ocean.parallel import DataParallel, HostStagedTransport
+        transport = HostStagedTransport() if rehearse else None
+        dp = DataParallel(model, learner, transport=transport)
+        transport = dp.transport
+    learner.use_hip_graph = not args.no_graph         # with ranks on RCCL the recorded step contains the collectives
     metrics, logs, nf, adj, labels = synth_inputs(B, T, N, N, rank, device)
     graph = ServiceGraph(adjacency_matrix=adj, node_features=nf)
 
@@ -184,14 +230,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    recorded = True
     for _ in range(max(args.warmup, 3 if learner.use_hip_graph else 0)):   # the graph is recorded on the third step
-        learner.process_tensors(metrics, graph, logs, labels)
+        try:
+            learner.process_tensors(metrics, graph, logs, labels)
+        except RuntimeError as e:
+            if not (use_dist and "recording the update step" in str(e)):
+                raise
+            # every rank runs the same code on the same shapes, so a recording that fails fails on all of them: they
+            # all go on with separate launches (the learner has switched recording off)
+            recorded = False
+            print(f"[rank {rank}] update step not recordable with its collectives, launching eagerly: {e.__cause__}", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         learner.process_tensors(metrics, graph, logs, labels)
     barrier()
     dt = time.perf_counter() - t0
+    graphed = bool(learner._graphed)
     # Roofline kernel timing: the library brackets each GEMM launch with HIP events on the launch stream.  That costs
     # host time per launch and sees nothing under HIP-graph replay, so it runs over a few eagerly launched steps after
     # the timed region (on every rank: the steps contain the collectives).
@@ -205,7 +262,7 @@ def main():
     _hip.profile_enable(False)
     if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        transport.all_reduce(t, "max")
         dt = float(t.item())
 
     if rank == 0:
@@ -215,16 +272,20 @@ def main():
         out = {
             "metric": "samples/sec fwd+bwd online step (256 svc, seq 128)",
             "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if args.weak else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2] (C3): {N} services (ER graph, in-degree 8), batch {B} per GPU, seq_len {T}, "
+            "config": {"workload": f"BASELINE configs[2] (C3): {N} services (ER graph, in-degree 8), global batch {world * B} "
+                                   f"({B} per GPU), seq_len {T}, "
                                    "online update step = fwd + BCE/InfoNCE(in-batch) loss + bwd + clip(1.0) + Adam, "
                                    "reference default hyper-parameters (dropout 0.1: every graph replica computed)",
-                       "global_batch": world * B, "seq_len": T, "services": N, "parallelism": f"dp{world}" + (" (rehearsal: all ranks on one GPU, gloo)" if rehearse else ""),
-                       "launch": "hip-graph replay" if learner._graphed else "eager"},
+                       "global_batch": world * B, "batch_per_gpu": B, "seq_len": T, "services": N,
+                       "parallelism": f"dp{world}" + (" (rehearsal: all ranks on one GPU, gloo)" if rehearse else ""),
+                       "launch": "hip-graph replay" + (" (collectives inside the graph)" if use_dist else "") if graphed else "eager"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": recorded_traffic(dom["kernel"]),
-                         "traffic_unit": "bytes/launch (HBM-side fetch+write, separate rocprofv3 --pmc passes)",
+                         "traffic_unit": "bytes/launch (HBM-side fetch+write, separate rocprofv3 --pmc passes of this command; "
+                                         "null unless recorded with this very library and script)",
                          "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "kernel": dom["kernel"],
                          "launches_per_step": dom["launches"] / prof_steps,
                          "avg_launch_ms": dom["total_ms"] / dom["launches"],
@@ -232,7 +293,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, nf, adj, T, N)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
