@@ -172,6 +172,8 @@ class _GraphedStep:
             opt.step(max_norm=clip if clip > 0 else 0.0)
             self.keys = [k for k in ("total_loss", "prediction_loss", "contrastive_loss") if torch.is_tensor(losses.get(k))]
             self.loss_vec = torch.stack([losses[k].detach().float().reshape(()) for k in self.keys])
+            if learner.data_parallel is not None:
+                self.loss_vec = learner.data_parallel.reduce_losses(self.loss_vec)
         self.outputs = outputs
         # recording advanced the host-side step counters of the parameters it updates without running anything: undo
         # that, for those parameters only (a frozen component has state from earlier steps but is not in this step)
@@ -235,7 +237,12 @@ class OnlineLearner:
     def _losses_to_host(self, losses: Dict[str, Any]) -> Dict[str, float]:
         """total / prediction / contrastive loss values with one device read."""
         keys = [k for k in ("total_loss", "prediction_loss", "contrastive_loss") if torch.is_tensor(losses.get(k))]
-        vals = torch.stack([losses[k].detach().float().reshape(()) for k in keys]).cpu().tolist() if keys else []
+        vals = []
+        if keys:
+            vec = torch.stack([losses[k].detach().float().reshape(()) for k in keys])
+            if self.data_parallel is not None:
+                vec = self.data_parallel.reduce_losses(vec)      # every rank reports (and schedules on) the global means
+            vals = vec.cpu().tolist()
         out = dict(zip(keys, vals))
         for k in ("total_loss", "prediction_loss", "contrastive_loss"):
             if k in losses and k not in out:
@@ -322,6 +329,17 @@ class OnlineLearner:
         labels = torch.stack([s.label for s in batch_samples])
         return self.process_tensors(metrics, service_graph, logs, labels)
 
+    def process_standin(self, seq_len: int, service_graph) -> Dict[str, float]:
+        """This rank's part in a data-parallel update for which it has no samples (sharded streams, uneven arrivals):
+        a one-row batch of zeros runs through the same kernels and collectives so that every rank's calls stay
+        matched; DataParallel.set_step_rows has told the wiring that the row counts as none (it adds nothing to the
+        BatchNorm statistics, the memory bank or - its loss weight being 0 - the gradients)."""
+        dev, m = self.model.device, self.model
+        metrics = torch.zeros(1, seq_len, m.metrics_input_dim, device=dev)
+        logs = torch.zeros(1, m.log_input_dim, device=dev)
+        labels = torch.zeros(1, m.config.model.num_services, device=dev)
+        return self.process_tensors(metrics, service_graph, logs, labels)
+
     def _take_staged(self, batch_samples):
         """Device tensors of this batch out of the pinned staging ring: the ones a previous call prefetched for
         this very list, or a fresh collate; None when staging does not apply."""
@@ -375,8 +393,8 @@ class OnlineLearner:
             return "the optimizer has several parameter groups"
         if self.grad_sync is not None and not getattr(self.data_parallel, "capturable", False):
             return "the gradient synchronisation hook's collectives cannot be captured (no RCCL transport)"
-        if self.data_parallel is not None and self.data_parallel.loss_weight() != 1.0:
-            return "the ranks hold different numbers of rows in this step"
+        if self.data_parallel is not None and getattr(self.data_parallel, "_rows_all", None) is not None:
+            return "sharded streams: the ranks' row counts change from step to step"
         if self.model.contrastive_negatives != "in_batch" and not getattr(
                 self.model.fusion_module.contrastive_module, "device_ring", False):
             return "memory-bank negatives with the ring pointer kept on the host"

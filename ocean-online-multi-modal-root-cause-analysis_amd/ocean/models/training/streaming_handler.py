@@ -8,6 +8,12 @@ worker that every `processing_interval` seconds drains up to `batch_size`
 samples per active stream and hands them to OnlineLearner.process_batch in
 chunks of `batch_size`, swallowing (and logging) per-batch exceptions.
 
+Sharding over data-parallel ranks (no counterpart in the reference, which is one process): every rank runs its own
+handler over the same set of streams; stream number s (in creation order) belongs to rank s mod world and only its
+owner buffers its samples.  A polling cycle starts with one small all-gather in which the ranks tell each other how
+many chunks they hold and of which sizes; all then run the largest chunk count, a rank that has run out of chunks
+taking part with a weightless stand-in batch, so that the collectives inside the update step stay matched.
+
 Addition (off by default): `event_driven=True` wakes the worker as soon as one
 stream holds `wake_samples` samples instead of at the next polling tick, so the
 delay between a window arriving and its update is the update time, not up to
@@ -138,9 +144,22 @@ class MemoryManager:
 
 
 class StreamProcessor:
+    MAX_CHUNKS = 62          # chunks per rank and cycle the agreement message has room for (64 streams x 32 samples)
+
     def __init__(self, online_learner: OnlineLearner, max_streams: int = 10, processing_interval: float = 1.0,
-                 batch_size: int = 32, event_driven: bool = False, wake_samples: Optional[int] = None):
+                 batch_size: int = 32, event_driven: bool = False, wake_samples: Optional[int] = None,
+                 data_parallel=None, service_graph=None):
         self.online_learner, self.max_streams = online_learner, max_streams
+        # sharding: the ocean.parallel.DataParallel that wires the learner's model (None: single process), and the
+        # service graph a rank uses for stand-in batches before it has seen a sample of its own
+        self.data_parallel = data_parallel if data_parallel is not None else getattr(online_learner, "data_parallel", None)
+        self.rank = self.data_parallel.rank if self.data_parallel is not None else 0
+        self.world = self.data_parallel.world if self.data_parallel is not None else 1
+        self.service_graph = service_graph
+        self._seq_len = 0
+        self._created = 0
+        self.owner: Dict[str, int] = {}
+        self.standin_steps = 0
         self.processing_interval, self.batch_size = processing_interval, batch_size
         self.event_driven = bool(event_driven)
         self.wake_samples = max(1, int(wake_samples if wake_samples is not None else batch_size))
@@ -164,6 +183,8 @@ class StreamProcessor:
             logger.warning("Stream %s already exists", stream.stream_id)
             return False
         self.streams[stream.stream_id] = stream
+        self.owner[stream.stream_id] = self._created % self.world      # creation order is the same on every rank
+        self._created += 1
         stream.is_active = True
         if self.event_driven:
             stream._on_sample = self._sample_arrived
@@ -177,8 +198,12 @@ class StreamProcessor:
     def _batch_waiting(self) -> bool:
         return any(s.is_active and len(s.buffer) >= self.wake_samples for s in list(self.streams.values()))
 
+    def owns(self, stream_id: str) -> bool:
+        return self.owner.get(stream_id, 0) == self.rank
+
     def remove_stream(self, stream_id: str) -> bool:
         stream = self.streams.pop(stream_id, None)
+        self.owner.pop(stream_id, None)
         if stream is None:
             return False
         stream.is_active = False
@@ -206,11 +231,16 @@ class StreamProcessor:
         t0 = time.time()
         samples: List[DatasetSample] = []
         for stream in list(self.streams.values()):
-            if stream.is_active:
+            if stream.is_active and self.owns(stream.stream_id):
                 samples.extend(stream.get_samples(self.batch_size))
-        if not samples:
+        if self.world > 1:
+            done = self._process_samples_sharded(samples)
+            if done == 0 and not samples:
+                return 0
+        elif not samples:
             return 0
-        done = self._process_samples(samples)
+        else:
+            done = self._process_samples(samples)
         self.processed_samples += done
         dt = time.time() - t0
         self.processing_times.append(dt)
@@ -256,6 +286,51 @@ class StreamProcessor:
                 logger.error("Error processing batch: %s", e)
         return done
 
+    def _process_samples_sharded(self, samples: List[DatasetSample]) -> int:
+        """One cycle of a rank among `world`: agree on the number of update steps (the largest chunk count of any rank)
+        and on every rank's chunk sizes, then run that many steps - real chunks while this rank has some, weightless
+        stand-in batches after that.  Every rank calls this once per cycle, with or without samples."""
+        import torch
+        dp = self.data_parallel
+        batches = [samples[i:i + self.batch_size] for i in range(0, len(samples), self.batch_size)][:self.MAX_CHUNKS]
+        if samples:
+            self._seq_len = int(samples[0].metrics.shape[0])
+            if self.service_graph is None:
+                self.service_graph = samples[0].graph
+        # message: [chunk count, sequence length, chunk sizes ...]; one all-gather over the ranks
+        msg = torch.zeros(2 + self.MAX_CHUNKS, dtype=torch.int64)
+        msg[0], msg[1] = len(batches), self._seq_len
+        for k, b in enumerate(batches):
+            msg[2 + k] = len(b)
+        dev = self.online_learner.model.device
+        table = torch.empty(self.world, msg.numel(), dtype=torch.int64, device=dev)
+        dp.transport.all_gather(table, msg.to(dev))
+        table = table.cpu()
+        n_steps = int(table[:, 0].max())
+        if n_steps == 0:
+            return 0
+        seq_len = int(table[:, 1].max())
+        done = 0
+        try:
+            for k in range(n_steps):
+                rows = [int(table[r, 2 + k]) for r in range(self.world)]
+                dp.set_step_rows(rows)
+                try:
+                    if k < len(batches):
+                        self.online_learner.process_batch(batches[k])
+                        done += len(batches[k])
+                    else:
+                        if self.service_graph is None:
+                            raise RuntimeError("a rank without samples needs the service graph for its stand-in batch: "
+                                               "pass service_graph= to StreamingHandler / StreamProcessor")
+                        self.online_learner.process_standin(seq_len, self.service_graph)
+                        self.standin_steps += 1
+                except Exception as e:      # logged and skipped like the reference does (streaming_handler.py:355-356);
+                    logger.error("Error processing batch: %s", e)     # the other ranks' collectives may now be unmatched
+        finally:
+            dp.set_step_rows(None)
+        return done
+
     def get_processing_stats(self) -> Dict[str, Any]:
         stats: Dict[str, Any] = {"total_processed_samples": self.processed_samples,
                                  "active_streams": sum(1 for s in self.streams.values() if s.is_active),
@@ -263,6 +338,9 @@ class StreamProcessor:
                                  "memory_stats": self.memory_manager.get_memory_stats()}
         if self.event_driven:
             stats.update({"event_driven": True, "wake_samples": self.wake_samples, "early_wakeups": self.early_wakeups})
+        if self.world > 1:
+            stats.update({"rank": self.rank, "world": self.world, "standin_steps": self.standin_steps,
+                          "owned_streams": sum(1 for sid in self.streams if self.owns(sid))})
         if self.processing_times:
             t = list(self.processing_times)
             stats.update({"avg_processing_time": np.mean(t), "max_processing_time": np.max(t), "processing_time_std": np.std(t)})
@@ -286,13 +364,15 @@ class StreamProcessor:
 
 class StreamingHandler:
     def __init__(self, online_learner: OnlineLearner, max_concurrent_streams: int = 10, processing_interval: float = 1.0,
-                 enable_memory_management: bool = True, event_driven: bool = False, wake_samples: Optional[int] = None):
+                 enable_memory_management: bool = True, event_driven: bool = False, wake_samples: Optional[int] = None,
+                 data_parallel=None, service_graph=None):
         self.online_learner = online_learner
         self.max_concurrent_streams, self.processing_interval = max_concurrent_streams, processing_interval
         self.enable_memory_management = enable_memory_management
         self.stream_processor = StreamProcessor(online_learner=online_learner, max_streams=max_concurrent_streams,
                                                 processing_interval=processing_interval, event_driven=event_driven,
-                                                wake_samples=wake_samples)
+                                                wake_samples=wake_samples, data_parallel=data_parallel,
+                                                service_graph=service_graph)
         self.stream_callbacks: Dict[str, Callable] = {}
         self.is_active = False
         self.start_time: Optional[datetime] = None
@@ -327,6 +407,8 @@ class StreamingHandler:
         stream = self.stream_processor.streams.get(stream_id)
         if stream is None:
             logger.warning("Stream %s not found", stream_id)
+            return False
+        if not self.stream_processor.owns(stream_id):     # sharded: another rank buffers and processes this stream
             return False
         ok = stream.add_sample(sample)
         cb = self.stream_callbacks.get(stream_id)

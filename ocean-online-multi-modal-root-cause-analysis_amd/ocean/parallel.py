@@ -61,7 +61,8 @@ class Transport:
         return dist.all_reduce(t, op=rop, group=self.group, async_op=async_op)
 
     def all_gather(self, out: torch.Tensor, x: torch.Tensor) -> None:
-        dist.all_gather_into_tensor(out, x.contiguous(), group=self.group)
+        """out (contiguous, world x the size of x) = the ranks' x one after the other, in rank order."""
+        dist.all_gather_into_tensor(out.view(-1), x.contiguous().view(-1), group=self.group)
 
     def reduce_scatter(self, out: torch.Tensor, x: torch.Tensor) -> None:
         if self.backend == "gloo":                            # gloo has no reduce_scatter: all-reduce, then slice
@@ -113,9 +114,9 @@ class HostStagedTransport(Transport):
         return _Done() if async_op else None
 
     def all_gather(self, out, x):
-        c = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(c, x.detach().cpu().contiguous(), group=self.group)
-        out.copy_(c)
+        c = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(c, x.detach().cpu().contiguous().view(-1), group=self.group)
+        out.copy_(c.view(out.shape))
 
     def reduce_scatter(self, out, x):
         c = x.detach().cpu().contiguous()
@@ -205,6 +206,7 @@ class DataParallel:
         # rows of this step: local, and summed over ranks (None: every rank holds the same number of rows)
         self._rows_local: Optional[int] = None
         self._rows_global: Optional[int] = None
+        self._rows_all: Optional[List[int]] = None
         params = [p for p in model.parameters() if p.requires_grad]
         if params and params[0].is_cuda:
             # arena order: the two encoders first, everything after them last, so that either part is one slice
@@ -225,8 +227,8 @@ class DataParallel:
         fm = getattr(model, "fusion_module", None)
         if fm is not None:
             cm = fm.contrastive_module
-            cm.gather_positives = lambda z: all_gather_rows(z, self.transport)
-            cm.rank_row_offset = lambda local_rows: self.rank * local_rows
+            cm.gather_positives = lambda z: z if self._rows_all is not None else all_gather_rows(z, self.transport)
+            cm.rank_row_offset = lambda local_rows: 0 if self._rows_all is not None else self.rank * local_rows
             cm.gather_bank_rows = self._gather_bank_rows
         if learner is not None:
             learner.grad_sync = self.sync_grads
@@ -236,11 +238,16 @@ class DataParallel:
                 lf.gather_rows = lambda x: all_gather_rows(x, self.transport)
 
     # ------------------------------------------------------------------ ragged steps
-    def set_step_rows(self, local_rows: Optional[int], global_rows: Optional[int]) -> None:
-        """Tell the wiring how many sample rows this rank and all ranks together hold in the coming step (sharded
-        streams: the ranks' batches differ in size, a rank may have none and then runs a stand-in batch with
-        local_rows = 0).  None, None: equal batches on every rank."""
-        self._rows_local, self._rows_global = local_rows, global_rows
+    def set_step_rows(self, rows_per_rank: Optional[List[int]]) -> None:
+        """Tell the wiring how many sample rows every rank holds in the coming step (sharded streams: the ranks'
+        batches differ in size; a rank with none runs a one-row stand-in batch that counts as 0 rows).  None: equal
+        batches on every rank (the default).  With unequal batches the in-batch InfoNCE negatives stay rank-local
+        (a gather needs equal row counts); memory-bank rows are gathered padded and written by their true counts."""
+        if rows_per_rank is None:
+            self._rows_local = self._rows_global = self._rows_all = None
+        else:
+            self._rows_all = [int(r) for r in rows_per_rank]
+            self._rows_local, self._rows_global = self._rows_all[self.rank], sum(self._rows_all)
 
     def loss_weight(self) -> float:
         """Factor for this rank's (local-mean) loss so that the rank-averaged gradient is the gradient of the mean
@@ -263,9 +270,18 @@ class DataParallel:
         single-process model would have written into the bank for the whole batch (graph_fusion.py:237-245), in its
         order.  No gradient (the bank is detached)."""
         M, B, P = rows.shape
-        out = torch.empty(self.world, M, B, P, device=rows.device, dtype=rows.dtype)
-        self.transport.all_gather(out.view(self.world * M, B, P), rows.detach().contiguous())
-        return out.permute(1, 0, 2, 3).reshape(M, self.world * B, P)
+        if self._rows_all is None:
+            out = torch.empty(self.world, M, B, P, device=rows.device, dtype=rows.dtype)
+            self.transport.all_gather(out.view(self.world * M, B, P), rows.detach().contiguous())
+            return out.permute(1, 0, 2, 3).reshape(M, self.world * B, P)
+        # unequal batches: every rank sends max-rows slots, the receivers keep each rank's true rows (a stand-in
+        # batch has one row and counts as none)
+        Bmax = max(max(self._rows_all), 1)
+        send = torch.zeros(M, Bmax, P, device=rows.device, dtype=rows.dtype)
+        send[:, :min(B, Bmax)] = rows.detach()[:, :Bmax]
+        out = torch.empty(self.world, M, Bmax, P, device=rows.device, dtype=rows.dtype)
+        self.transport.all_gather(out.view(self.world * M, Bmax, P), send)
+        return torch.cat([out[r, :, :n] for r, n in enumerate(self._rows_all)], dim=1)
 
     # ------------------------------------------------------------------ gradients
     def _watch_encoder_output(self, module, inputs, output):
@@ -276,8 +292,18 @@ class DataParallel:
         """Runs inside backward, when the gradient of the temporal encoder's output is known: every stage after the
         encoders has finished its backward, i.e. has written its parameter gradients into the arena."""
         if self._early_work is None and self.arena is not None and self._split:
+            if self._rows_local == 0:
+                self.arena.flat[self._split:].zero_()          # a stand-in batch contributes no gradient (see sync_grads)
             self._early_work = self.transport.all_reduce(self.arena.flat[self._split:], "avg", async_op=True)
         return None
+
+    def reduce_losses(self, vec: torch.Tensor) -> torch.Tensor:
+        """Local mean losses [k] -> the means over all rows of the step, identical on every rank (one small
+        all-reduce).  The learner feeds these to its learning-rate policy, which must not diverge between ranks."""
+        w = self.loss_weight()
+        vec = vec * w if w != 1.0 else vec.clone()
+        self.transport.all_reduce(vec, "avg")
+        return vec
 
     def sync_grads(self, model=None) -> None:
         model = model or self.model
@@ -297,9 +323,17 @@ class DataParallel:
                 self._early_work = None
             self.bucket.all_reduce_mean(grads)
             return
+        # A stand-in batch (no rows of its own this step) must add nothing.  Its loss weight is 0, but the synchronised
+        # BatchNorm backward still hands its row the batch-mean terms of the OTHER ranks' gradients (its row took no
+        # part in the statistics those terms belong to): its gradients are zero by definition, so they are zeroed.
+        standin = self._rows_local == 0
         if self._early_work is not None:
+            if standin:
+                a.flat[:self._split].zero_()
             self.transport.all_reduce(a.flat[:self._split], "avg")
             self._early_work.wait()
             self._early_work = None
         else:
+            if standin:
+                a.flat.zero_()
             self.transport.all_reduce(a.flat, "avg")

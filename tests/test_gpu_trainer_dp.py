@@ -278,3 +278,97 @@ def test_data_parallel_class_on_one_rccl_rank_eager_and_recorded():
         assert abs(a - b) <= 1e-4 * abs(a), (r["eager_hist"], r["graph_hist"])
     for a, b in zip(r["eager_params"], r["graph_params"]):
         close(b, a, 3e-3)
+
+
+def _shard_gpu_worker(rank, world, port, fix, out):
+    import faulthandler
+    from datetime import datetime as dt
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(120, exit=True)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ocean
+        from ocean.data import DatasetSample, ServiceGraph
+        from ocean.models.training import OnlineLearner, StreamingHandler
+        from ocean.parallel import DataParallel, HostStagedTransport
+        cfg = tiny_config()
+        m = ocean.OCEANModel(cfg)
+        zero_dropout(m)
+        m.load_state_dict({k: v.clone() for k, v in fix["sd"].items()})
+        m = m.cuda()
+        m.contrastive_negatives = "bank"
+        learner = OnlineLearner(m, cfg)
+        dp = DataParallel(m, learner, transport=HostStagedTransport())
+        sg = ServiceGraph(fix["adj"], fix["nf"])
+        h = StreamingHandler(learner, max_concurrent_streams=4, processing_interval=0.05, service_graph=sg)
+        h.stream_processor.batch_size = 4
+        for s in range(4):
+            h.create_stream(f"s{s}")
+        # rank 0 owns s0 (samples 0..3) and s2 (sample 4): chunks of 4 and 1; rank 1 owns s1 (samples 5..7): one chunk of 3
+        for i in range(8):
+            smp = DatasetSample(fix["metrics"][i], fix["logs"][i], sg, fix["labels"][i], dt(2024, 1, 1))
+            h.add_sample_to_stream("s0" if i < 4 else ("s2" if i == 4 else "s1"), smp)
+        done = h.stream_processor.process_once()
+        torch.cuda.synchronize()
+        cm = m.fusion_module.contrastive_module
+        out[rank] = {"done": done, "updates": learner.update_count, "hist": list(learner.performance_history["batch_loss"]),
+                     "params": {k: v.detach().cpu() for k, v in m.state_dict().items()},
+                     "standins": h.stream_processor.standin_steps}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_streams_two_ranks_uneven_arrivals_match_the_union_batches():
+    """Two ranks, uneven arrivals on their streams (5 and 3 samples, chunks of 4): step 0 trains on rank 0's 4 rows and
+    rank 1's 3, step 1 on rank 0's last row while rank 1 takes part with a weightless stand-in.  With memory-bank
+    negatives every coupling is exact (BatchNorm statistics over the real rows of both ranks, losses and gradients
+    weighted by row counts, the ranks' projections written into the ring in rank order), so both ranks must end with
+    the same state as ONE process that takes two update steps on the union batches [0-3, 5-7] and [4]."""
+    import torch.multiprocessing as mp
+    fix = _fixture()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_shard_gpu_worker, args=(2, _free_port(), fix, out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert (a["done"], b["done"]) == (5, 3) and a["updates"] == b["updates"] == 2
+    assert (a["standins"], b["standins"]) == (0, 1)
+    assert a["hist"] == b["hist"]                                    # the all-reduced global means, identical on both ranks
+    for k in a["params"]:
+        assert torch.equal(a["params"][k], b["params"][k]), k        # same averaged gradients, same update, same bank
+    # one process on the union batches
+    rsd = R.require_grad(fix["sd"])
+    tk = R.trainable_keys(rsd)
+    state = {k: {} for k in tk}
+    ref_hist = []
+    for rows in ([0, 1, 2, 3, 5, 6, 7], [4]):
+        for k in tk:
+            rsd[k].grad = None
+        ro = R.model_forward(rsd, fix["metrics"][rows], fix["adj"], fix["nf"], fix["logs"][rows], training=True, negatives="bank",
+                             dilations=(1, 2), gnn_heads=2, log_dim=24)
+        rl = R.compute_loss(ro, fix["labels"][rows])
+        rl["total_loss"].backward()
+        ref_hist.append(float(rl["total_loss"]))
+        # the dead query / key projections of the length-1 self-attentions get exact-zero gradients in the reference
+        # (and on the HIP path), so Adam's weight decay moves them; the oracle leaves them out of its graph
+        for k in tk:
+            if "_self_attention.w_q." in k or "_self_attention.w_k." in k:
+                rsd[k].grad = torch.zeros_like(rsd[k])
+        wg = [k for k in tk if rsd[k].grad is not None]
+        R.clip_grad_norm([rsd[k].grad for k in wg], 1.0)
+        with torch.no_grad():
+            R.adam_step([rsd[k] for k in wg], [rsd[k].grad for k in wg], [state[k] for k in wg])
+    for got, ref in zip(a["hist"], ref_hist):
+        assert abs(got - ref) <= 1e-3 * abs(ref), (a["hist"], ref_hist)
+    c = "fusion_module.contrastive_module."
+    assert int(a["params"][c + "memory_ptr"]) == int(rsd[c + "memory_ptr"])
+    close(a["params"][c + "memory_bank"], rsd[c + "memory_bank"], 2e-3)
+    for k in ("temporal_encoder.conv_layers.1.batch_norm.running_mean", "temporal_encoder.conv_layers.0.batch_norm.running_var"):
+        close(a["params"][k], rsd[k], 1e-3)
+    for k in tk:
+        if rsd[k].is_floating_point():
+            # two Adam steps move an element by up to 2 lr = 2e-3 whatever its gradient's size (elements whose true
+            # gradient is ~0, like a bias in front of a BatchNorm, can land anywhere in that range); on average the
+            # tensors agree far more closely
+            d = (a["params"][k].double() - rsd[k].detach().double()).abs()
+            assert float(d.max()) <= 2.1e-3 and float(d.mean()) <= 5e-4, (k, float(d.max()), float(d.mean()))

@@ -116,3 +116,78 @@ def test_data_parallel_wiring_broadcasts_and_averages():
     out = mgr.dict()
     mp.spawn(_wire_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: (True, True, True, True), 1: (True, True, True, True)}
+
+
+class _ShardStubLearner:
+    """Records what the sharded stream processor asks of it (no model arithmetic)."""
+
+    class _M:
+        device = torch.device("cpu")
+
+    def __init__(self):
+        self.model, self.calls = self._M(), []
+
+    def process_batch(self, batch, prefetch=None):
+        self.calls.append(("batch", len(batch)))
+        return {}
+
+    def process_standin(self, seq_len, graph):
+        self.calls.append(("standin", seq_len))
+        return {}
+
+
+class _ShardStubDP:
+    def __init__(self):
+        from ocean.parallel import Transport
+        self.transport = Transport()
+        self.rank, self.world = self.transport.rank, self.transport.world
+        self.rows = []
+
+    def set_step_rows(self, rows):
+        self.rows.append(rows)
+
+
+def _shard_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from ocean.models.training import StreamingHandler
+        learner, dp = _ShardStubLearner(), _ShardStubDP()
+        h = StreamingHandler(learner, max_concurrent_streams=4, processing_interval=0.05, data_parallel=dp, service_graph="G")
+        for s in range(4):
+            assert h.create_stream(f"s{s}", buffer_size=100)
+        sp = h.stream_processor
+        owned = [sid for sid in sp.streams if sp.owns(sid)]
+        sample = lambda: SimpleNamespace(metrics=torch.zeros(9, 3), graph="G")
+        # rank 0 receives 2 x 35 samples on its streams (s0, s2), rank 1 10 on one of its (s1); samples offered to a stream
+        # another rank owns are turned away
+        accepted = 0
+        for sid, n in (("s0", 35), ("s2", 35), ("s1", 10)):
+            for _ in range(n):
+                accepted += bool(h.add_sample_to_stream(sid, sample()))
+        done1 = sp.process_once()          # rank 0: 32 + 32 taken -> chunks 32, 32; rank 1: 10 -> one chunk
+        done2 = sp.process_once()          # rank 0: the remaining 3 + 3; rank 1: nothing -> one stand-in
+        done3 = sp.process_once()          # nobody has anything: no step at all
+        out[rank] = {"owned": owned, "accepted": accepted, "done": (done1, done2, done3), "calls": learner.calls,
+                     "rows": dp.rows, "standins": sp.get_processing_stats()["standin_steps"]}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_streams_agree_on_step_counts():
+    """Streams are dealt to ranks round-robin; per cycle the ranks run the same number of update steps (the largest
+    chunk count), a rank that has run out taking part with stand-in batches, and every rank knows every rank's row
+    count of every step (ocean/models/training/streaming_handler.py:303-358 is the single-process loop this extends)."""
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_shard_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["owned"] == ["s0", "s2"] and r1["owned"] == ["s1", "s3"]
+    assert r0["accepted"] == 70 and r1["accepted"] == 10
+    assert r0["done"] == (64, 6, 0) and r1["done"] == (10, 0, 0)
+    assert r0["calls"] == [("batch", 32), ("batch", 32), ("batch", 6)]
+    assert r1["calls"] == [("batch", 10), ("standin", 9), ("standin", 9)]
+    # both ranks saw the same per-step row tables, and switched the weighting off again after each cycle
+    assert r0["rows"] == r1["rows"] == [[32, 10], [32, 0], None, [6, 0], None]
+    assert r0["standins"] == 0 and r1["standins"] == 2
