@@ -56,6 +56,21 @@ __device__ __forceinline__ DropoutP dropout_resolve(DropoutP d) {
   return d;
 }
 #endif
+// the same hash for element indices below 2^32 (idx >> 32 == 0), without 64-bit index arithmetic
+__host__ __device__ inline uint32_t ocean_hash32_lo(uint64_t seed, uint32_t idx) {
+  uint32_t h = idx * 0x9E3779B1u + (uint32_t)seed;
+  h ^= h >> 15;
+  h += (uint32_t)(seed >> 32);
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  h *= 0x297A2D39u;
+  h ^= h >> 15;
+  return h;
+}
+__host__ __device__ inline float dropout_keep_lo(const DropoutP& d, uint32_t idx) {
+  const float u = (float)(ocean_hash32_lo(d.seed, idx) >> 8) * (1.0f / 16777216.0f);
+  return u >= d.p ? 1.0f / (1.0f - d.p) : 0.0f;
+}
 // multiplier applied to a surviving / dropped activation: 1/(1-p) or 0
 __host__ __device__ inline float dropout_keep(const DropoutP& d, uint64_t idx) {
   const float u = (float)(ocean_hash32(d.seed, idx) >> 8) * (1.0f / 16777216.0f);   // [0,1)
@@ -101,9 +116,22 @@ struct GemmP {
   int ld_mask;
   float* a_colsum;          // row reductions (a_kmajor) with one tap only: a_colsum[m] += sum_k A[k][m], the bias gradient of a
                             // linear layer whose weight gradient this launch computes; or null
+  // BatchNorm-backward column sums on the way out (non-reducing launches; null bn_u: off).  The output C[row][col] is
+  // the gradient dy of a layer y = dropout(relu(u * scale + shift)) whose pre-normalisation values u [M, N] the
+  // forward pass kept: with g = dy * [u*scale+shift > 0] * keep(row*N + col), the launch adds sum_rows g and
+  // sum_rows g * (u - mean) * invstd per column into bn_slots [slots][2][N] (fp64, slot = row tile % slots), which
+  // is what a separate pass over dy and u would otherwise compute.  C itself is stored unmasked.
+  const float* bn_u; int ld_bn_u;
+  const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd;
+  double* bn_slots; int bn_nslots;
+  DropoutP bn_drop;
 };
 
 int ocean_launch_gemm(const GemmP& p, hipStream_t stream);
+// whether a launch of `p` (data-gradient form, bn_* fields aside) can carry the BatchNorm-backward column sums in its
+// epilogue: every output tile full, a broadcast residual constant per tile, element indices within 32 bits.  Set the
+// bn_* fields only when this holds.
+bool ocean_gemm_bn_rides(const GemmP& p);
 
 // Up to kGemmBatchMax independent problems of the same operand storage mode (a_kmajor / b_kn) and tap count in ONE
 // launch (blockIdx.y selects the problem): the independent modality branches of the attention and fusion
@@ -124,5 +152,7 @@ static inline GemmP gemm_defaults() {
   p.tap_stride_b = 0; p.tap_stride_c = 0; p.split_k = 1; p.bias = nullptr; p.a_colsum = nullptr; p.drop = DropoutP{0.f, 0, nullptr}; p.drop_group = 1; p.drop_row0 = 0;
   p.relu_mask = nullptr; p.ld_mask = 0; p.R = nullptr; p.ldr = 0; p.r_bcast_T = 0; p.r_scale = 1.f;
   p.relu = 0; p.colstats = nullptr; p.colstat_slots = 1;
+  p.bn_u = nullptr; p.ld_bn_u = 0; p.bn_scale = p.bn_shift = p.bn_mean = p.bn_invstd = nullptr; p.bn_slots = nullptr; p.bn_nslots = 1;
+  p.bn_drop = DropoutP{0.f, 0, nullptr};
   return p;
 }

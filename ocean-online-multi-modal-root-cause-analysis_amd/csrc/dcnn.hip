@@ -528,7 +528,6 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
     const float* dy = last ? wb + pl.dpool : grad_buf(j);
     const int bT = last ? s->T : 0;
     const float sc = last ? 1.0f / (float)s->T : 1.0f;
-    double* bs = reinterpret_cast<double*>(wb + pl.bstats[j]);
     double* slots = reinterpret_cast<double*>(wb + pl.bslots[j]);
     // about 1024 row blocks: every block ends with 2*C fp64 atomics, and measured over 256..8192 blocks the pass is
     // fastest here (fewer blocks leave CUs idle at the tail, more pile up on the atomics)
@@ -543,11 +542,30 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
                          wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], slots, M, C, ct, layer_dropout(s, j));
     }
     OCEAN_LAUNCH_CHECK();
-    // gamma / beta gradients come from THIS rank's sums (before any cross-rank all-reduce of the block), so that
-    // averaging parameter gradients over ranks yields the global-batch gradient like every other parameter
-    hipLaunchKernelGGL(bn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, slots, bs, grads[pi_bn(pl, j, 1)], grads[pi_bn(pl, j, 2)], C);
+    return OCEAN_OK;
+  };
+  // the column sums of layer j are complete in their slots (from `reduce`, or from the epilogue of the data-gradient
+  // GEMM that produced the layer's dy): fold the slots, and take the gamma / beta gradients from THIS rank's sums
+  // (before any cross-rank all-reduce of the block), so that averaging parameter gradients over ranks yields the
+  // global-batch gradient like every other parameter
+  auto reduce_finish = [&](int j) -> int {
+    const int C = pl.width[j];
+    hipLaunchKernelGGL(bn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, reinterpret_cast<double*>(wb + pl.bslots[j]),
+                       reinterpret_cast<double*>(wb + pl.bstats[j]), grads[pi_bn(pl, j, 1)], grads[pi_bn(pl, j, 2)], C);
     OCEAN_LAUNCH_CHECK();
     return OCEAN_OK;
+  };
+  // BatchNorm-backward sums of layer j-1 ride in the epilogue of layer j's data-gradient GEMM, whose output is that
+  // layer's dy (it is in registers there; a separate pass would read it and u again from memory)
+  static const bool fuse_reduce = getenv("OCEAN_DCNN_SEPARATE_BN_REDUCE") == nullptr;     // measurement switch
+  auto ride_along = [&](GemmP& g, int jprev) -> bool {
+    if (!fuse_reduce || !ocean_gemm_bn_rides(g)) return false;
+    g.bn_u = wf + pl.u[jprev]; g.ld_bn_u = pl.width[jprev];
+    g.bn_scale = wf + pl.scale[jprev]; g.bn_shift = wf + pl.shift[jprev];
+    g.bn_mean = wf + pl.mean[jprev]; g.bn_invstd = wf + pl.invstd[jprev];
+    g.bn_slots = reinterpret_cast<double*>(wb + pl.bslots[jprev]); g.bn_nslots = kStatSlots;
+    g.bn_drop = layer_dropout(s, jprev);
+    return true;
   };
 
   for (int ph = phase_lo; ph < phase_hi; ++ph) {
@@ -557,6 +575,7 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
       OCEAN_TRY(linear_bwd_weight(dout, s->out_dim, wf + pl.pooled, Cl, grads[pi_out(L, 0)], s->B, s->out_dim, Cl, st, grads[pi_out(L, 1)]));   // + bias gradient (column sums of the same operand)
       OCEAN_TRY(linear_bwd_data(dout, s->out_dim, params[pi_out(L, 0)], wb + pl.dpool, Cl, s->B, s->out_dim, Cl, 0, st));
       OCEAN_TRY(reduce(pl.nbn - 1));
+      OCEAN_TRY(reduce_finish(pl.nbn - 1));
       continue;
     }
     const int j = pl.nbn - ph;          // BN layer finished in this phase
@@ -578,6 +597,7 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
     }
     OCEAN_LAUNCH_CHECK();
     const float* in = layer_input(pl, j, wf);
+    bool rode = false;
     if (pl.is_block[j]) {
       const int i = pl.li[j], k = s->kernel_size, d = s->dilations[i];
       // weight gradient per tap into the packed buffer
@@ -595,14 +615,20 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
       h.C = gout; h.ldc = Cin;
       if (last) { h.R = wb + pl.dpool; h.ldr = Cl; h.r_bcast_T = s->T; h.r_scale = 1.0f / (float)s->T; }
       else { h.R = gout; h.ldr = Cin; }
+      if (j > 0) rode = ride_along(h, j - 1);
       OCEAN_TRY(ocean_launch_gemm(h, st));
     } else {
       const int i = pl.li[j];
       OCEAN_TRY(linear_bwd_weight(dU, C, in, Cin, grads[pi_trans(L, i, 0)], M, C, Cin, st));
-      OCEAN_TRY(linear_bwd_data(dU, C, params[pi_trans(L, i, 0)], grad_buf(j - 1), Cin, M, C, Cin, 0, st));
+      GemmP h = gemm_defaults();        // dx = dU . W   (W [C, Cin] read as [k][n])
+      h.A = dU; h.lda = C; h.B = params[pi_trans(L, i, 0)]; h.ldb = Cin; h.b_kn = 1; h.C = grad_buf(j - 1); h.ldc = Cin;
+      h.M = M; h.N = Cin; h.K = C;
+      rode = ride_along(h, j - 1);
+      OCEAN_TRY(ocean_launch_gemm(h, st));
     }
     if (j > 0) {
-      OCEAN_TRY(reduce(j - 1));
+      if (!rode) OCEAN_TRY(reduce(j - 1));
+      OCEAN_TRY(reduce_finish(j - 1));
     } else {
       // input projection: grad wrt h0 sits in grad_buf(0)
       const float* dh0 = grad_buf(0);

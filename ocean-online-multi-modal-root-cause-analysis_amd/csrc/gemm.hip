@@ -47,8 +47,11 @@ __device__ __forceinline__ int xcd_swizzle(int orig, int nwg) {
 #define OCEAN_SINGLE_LDS_OPS
 #endif
 
-template <int BM, int BN, int BK, bool AKM, bool BKN, bool ALIGNED>
-__global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel(const GemmBatch batch) {
+// BNS: the launch also accumulates the BatchNorm-backward column sums described at GemmP::bn_u.  A template parameter,
+// not a run-time test: the extra epilogue state must not count towards the register allocation of the other
+// instantiations, whose three waves per SIMD depend on staying within 168 registers.
+template <int BM, int BN, int BK, bool AKM, bool BKN, bool ALIGNED, bool BNS = false>
+__global__ __launch_bounds__(kThreads, 3) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel(const GemmBatch batch) {
   const GemmP& p = batch.g[blockIdx.y];
   constexpr int WN = 2;
   constexpr int TM = BM / 2 / 32, TN = BN / 2 / 32;
@@ -409,8 +412,13 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
   struct {
     float* C; int M, N; const float* R; const float* bias; int colstat_slots; double* colstats; DropoutP drop;
     int drop_group, drop_row0, ld_mask, ldc, ldr, r_bcast_T; float r_scale; int relu; const float* relu_mask; long tap_stride_c;
+    const float* bn_u; int ld_bn_u; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd;
+    double* bn_slots; int bn_nslots;
   } e = {p.C, p.M, p.N, p.R, p.bias, p.colstat_slots, p.colstats, p.drop, p.drop_group, p.drop_row0, p.ld_mask, p.ldc, p.ldr,
-         p.r_bcast_T, p.r_scale, p.relu, p.relu_mask, (long)p.tap_stride_c};
+         p.r_bcast_T, p.r_scale, p.relu, p.relu_mask, (long)p.tap_stride_c,
+         p.bn_u, p.ld_bn_u, p.bn_scale, p.bn_shift, p.bn_mean, p.bn_invstd, p.bn_slots, p.bn_nslots};
+  const DropoutP bn_drop = BNS ? dropout_resolve(p.bn_drop) : DropoutP{0.f, 0, nullptr};
+  constexpr bool bn_on = BNS && !AKM;
   // acc register r of lane l holds C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile.
   float* Cz = e.C + (AKM ? (long)ztap * e.tap_stride_c : 0);
   const DropoutP drop = dropout_resolve(e.drop);
@@ -504,12 +512,15 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
     const uint32_t r_lane = ((uint32_t)(4 * khalf) * (uint32_t)e.ldr + lcol) * 4u;
     const bool has_r = !atomic_out && e.R != nullptr;
     const float floor_v = e.relu ? 0.f : -__builtin_inff();
-    const char* r_w = (const char*)(e.R + (has_r ? (long)row_w * e.ldr + col_w : 0));
+    const char* r_w = (const char*)(e.R + ((has_r && e.r_bcast_T <= 0) ? (long)row_w * e.ldr + col_w : 0));
     char* c_w = (char*)(Cz + (long)row_w * e.ldc + col_w);
     const uint32_t c_pitch = (uint32_t)e.ldc * 4u, r_pitch = (uint32_t)e.ldr * 4u;
     // buffer instructions take the wave-uniform part of the address as a scalar offset operand
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(c_w, 0, 0x7FFFFFF0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(r_w), 0, 0x7FFFFFF0, 0x00020000);
+    const char* u_w = (const char*)(bn_on ? e.bn_u + (long)row_w * e.ld_bn_u + col_w : e.C);
+    const uint32_t u_lane = ((uint32_t)(4 * khalf) * (uint32_t)e.ld_bn_u + lcol) * 4u, u_pitch = (uint32_t)e.ld_bn_u * 4u;
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(u_w), 0, 0x7FFFFFF0, 0x00020000);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col_u = col_w + j * 32;
@@ -528,32 +539,84 @@ __global__ __launch_bounds__(kThreads) OCEAN_SINGLE_LDS_OPS void gemm_f32_kernel
         }
       }
       const float bias = e.bias != nullptr ? e.bias[col_u + lcol] : 0.f;
+      float bn_sc = 0.f, bn_sh = 0.f, bn_mu = 0.f, bn_is = 0.f, bn_sg = 0.f, bn_sx = 0.f;
+      if (bn_on) { bn_sc = e.bn_scale[col_u + lcol]; bn_sh = e.bn_shift[col_u + lcol]; bn_mu = e.bn_mean[col_u + lcol]; bn_is = e.bn_invstd[col_u + lcol]; }
+      const uint32_t bn_idx_lane = 4u * (uint32_t)khalf * (uint32_t)e.N + (uint32_t)(col_u + lcol);
+      // residual broadcast from one row per sample: the host sends such a launch here only when a tile lies inside one
+      // sample (T % BM == 0), so the row is block-uniform and the value depends on the column alone
+      const bool bcast_r = bn_on && has_r && e.r_bcast_T > 0;
+      const float rb_val = bcast_r ? e.r_scale * e.R[(long)(m0 / e.r_bcast_T) * e.ldr + col_u + lcol] : 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        // the sixteen residual values of a 32x32 sub-tile are requested together: one memory round trip, not four
-        float rv[16];
+        if constexpr (!bn_on) {
+          // the sixteen residual values of a 32x32 sub-tile are requested together: one memory round trip, not four
+          float rv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-        if (has_r) {
+          for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+          if (has_r) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                rs_r, (int)r_lane, (int)((uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3)) * r_pitch + (uint32_t)(j * 128)), 0));
+            for (int r = 0; r < 16; ++r)
+              rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  rs_r, (int)r_lane, (int)((uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3)) * r_pitch + (uint32_t)(j * 128)), 0));
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const uint32_t c_soff = (uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3)) * c_pitch + (uint32_t)(j * 128);
+            const float v = acc[i][j][r] + bias;
+            if (atomic_out) unsafeAtomicAdd((float*)(c_w + (size_t)c_soff + c_lane), v);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(v + rv[r], floor_v)), rs_c, (int)c_lane, (int)c_soff, 0);
+          }
+        } else {
+          // with the BatchNorm sums riding along: four values at a time (residual and saved u of the same elements), so
+          // that the live registers stay within what the main loop needs anyway
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            float rv[4], uv[4];
+#pragma unroll
+            for (int r8 = 0; r8 < 4; ++r8) {
+              const int r = rq * 4 + r8;
+              const uint32_t roff = (uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3));
+              rv[r8] = bcast_r ? rb_val : (has_r ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)r_lane, (int)(roff * r_pitch + (uint32_t)(j * 128)), 0)) : 0.f);
+              uv[r8] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_u, (int)u_lane, (int)(roff * u_pitch + (uint32_t)(j * 128)), 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r8 = 0; r8 < 4; ++r8) {
+              const int r = rq * 4 + r8;
+              const uint32_t roff = (uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3));
+              const float out = fmaxf(acc[i][j][r] + bias + rv[r8], floor_v);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out), rs_c, (int)c_lane, (int)(roff * c_pitch + (uint32_t)(j * 128)), 0);
+              float g = (fmaf(uv[r8], bn_sc, bn_sh) > 0.f) ? out : 0.f;
+              if (bn_drop.p > 0.f) {
+                // element index row * N + col; the host sends a launch here only when M * N < 2^32
+                g *= dropout_keep_lo(bn_drop, ((uint32_t)row_w + roff) * (uint32_t)e.N + bn_idx_lane);
+              }
+              bn_sg += g;
+              bn_sx += g * (uv[r8] - bn_mu) * bn_is;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const uint32_t c_soff = (uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3)) * c_pitch + (uint32_t)(j * 128);
-          const float v = acc[i][j][r] + bias;
-          if (atomic_out) unsafeAtomicAdd((float*)(c_w + (size_t)c_soff + c_lane), v);
-          else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(v + rv[r], floor_v)), rs_c, (int)c_lane, (int)c_soff, 0);
+      }
+      if (bn_on) {
+        bn_sg += __shfl_xor(bn_sg, 32);
+        bn_sx += __shfl_xor(bn_sx, 32);
+        if (lane < 32) {
+          double* bs = e.bn_slots + (size_t)(tile_m % e.bn_nslots) * 2 * e.N + col_u;
+          unsafeAtomicAdd(bs + lcol, (double)bn_sg);
+          unsafeAtomicAdd(bs + e.N + lcol, (double)bn_sx);
         }
       }
     }
   };
-  const bool extra = !AKM && (drop.p > 0.f || e.relu_mask != nullptr);
-  if (extra) epilogue(std::true_type{});
-  else if (m0 + BM <= e.M && n0 + BN <= e.N && e.r_bcast_T <= 0) epilogue_full();
-  else epilogue(std::false_type{});
+  if constexpr (BNS) {
+    epilogue_full();       // the host checked: every tile is full, no output dropout / mask (ocean_gemm_bn_rides)
+  } else {
+    const bool extra = !AKM && (drop.p > 0.f || e.relu_mask != nullptr);
+    if (extra) epilogue(std::true_type{});
+    else if (m0 + BM <= e.M && n0 + BN <= e.N && e.r_bcast_T <= 0) epilogue_full();
+    else epilogue(std::false_type{});
+  }
 }
 
 template <int BM, int BN, int BK, bool AKM, bool BKN>
@@ -577,7 +640,16 @@ int launch_cfg(const GemmBatch& b, bool aligned, hipStream_t stream) {
     ocean_prof_begin(name, flops, bytes, stream, &tok);
   }
   static const int dyn_lds = [] { const char* e = getenv("OCEAN_GEMM_DYNLDS"); return e ? atoi(e) : 0; }();   // occupancy experiments
-  if (aligned) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, true>), grid, dim3(kThreads), dyn_lds, stream, b);
+  bool launched = false;
+  if constexpr (!AKM && BKN) {       // the data-gradient form may carry BatchNorm-backward sums in its epilogue
+    if (b.g[0].bn_u != nullptr) {
+      if (aligned) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, true, true>), grid, dim3(kThreads), dyn_lds, stream, b);
+      else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, false, true>), grid, dim3(kThreads), dyn_lds, stream, b);
+      launched = true;
+    }
+  }
+  if (launched) {}
+  else if (aligned) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, true>), grid, dim3(kThreads), dyn_lds, stream, b);
   else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, AKM, BKN, false>), grid, dim3(kThreads), dyn_lds, stream, b);
   ocean_prof_end(tok, stream);
   OCEAN_LAUNCH_CHECK();
@@ -595,10 +667,9 @@ inline int wg_chunk() { static const int v = env_int("OCEAN_GEMM_WG_CHUNK", 128)
 inline int wg_atom_div() { static const int v = env_int("OCEAN_GEMM_WG_ATOMDIV", 2); return v; }
 inline long wg_big_k() { static const int v = env_int("OCEAN_GEMM_WG_BIGK", 8192); return v; }
 
-template <bool AKM, bool BKN>
-int launch_mode(GemmBatch b, bool aligned, hipStream_t stream) {
-  // tile choice from the largest problem: wide tiles only when they still fill the chip
-  int M = 0, N = 0, K = 0, taps = b.g[0].taps;
+// tile choice from the largest problem of a batch: wide tiles only when they still fill the chip
+void pick_tile(const GemmBatch& b, bool akm, int* bm_out, int* bn_out, int* k_out) {
+  int M = 0, N = 0, K = 0;
   long tiles128 = 0;
   for (int q = 0; q < b.n; ++q) {
     if (b.g[q].M > M) M = b.g[q].M;
@@ -608,10 +679,18 @@ int launch_mode(GemmBatch b, bool aligned, hipStream_t stream) {
   }
   const bool big_m = tiles128 >= 256;
   int bm, bn;
-  if (AKM && M >= 128 && N >= 128 && K >= wg_big_k()) { bm = 128; bn = 128; }   // long row reductions fill the chip through split-K
-  else if (!AKM && N > 64 && big_m) { bm = 128; bn = 128; }
-  else if (!AKM && N <= 64 && (long)ceil_div(M, 128) * b.n >= 256) { bm = 128; bn = 64; }
+  if (akm && M >= 128 && N >= 128 && K >= wg_big_k()) { bm = 128; bn = 128; }   // long row reductions fill the chip through split-K
+  else if (!akm && N > 64 && big_m) { bm = 128; bn = 128; }
+  else if (!akm && N <= 64 && (long)ceil_div(M, 128) * b.n >= 256) { bm = 128; bn = 64; }
   else { bm = 64; bn = 64; }
+  *bm_out = bm; *bn_out = bn; *k_out = K;
+}
+
+template <bool AKM, bool BKN>
+int launch_mode(GemmBatch b, bool aligned, hipStream_t stream) {
+  int bm, bn, K;
+  const int taps = b.g[0].taps;
+  pick_tile(b, AKM, &bm, &bn, &K);
   if (AKM) {
     int split = b.g[0].split_k;
     if (split <= 0) {
@@ -683,3 +762,15 @@ int ocean_launch_gemm_batch(const GemmP* ps, int n, hipStream_t stream) {
 }
 
 int ocean_launch_gemm(const GemmP& p, hipStream_t stream) { return ocean_launch_gemm_batch(&p, 1, stream); }
+
+bool ocean_gemm_bn_rides(const GemmP& p) {
+  if (p.a_kmajor || !p.b_kn || p.drop.p > 0.f || p.relu_mask != nullptr || p.bias != nullptr) return false;
+  GemmBatch b;
+  b.n = 1; b.g[0] = p;
+  int bm, bn, K;
+  pick_tile(b, false, &bm, &bn, &K);
+  if (p.M % bm != 0 || p.N % bn != 0) return false;                      // every tile full: the variant has no bounds tests
+  if (p.r_bcast_T > 0 && (p.R == nullptr || p.r_bcast_T % bm != 0)) return false;   // a tile inside one sample
+  if ((double)p.M * (double)p.N >= 4294967296.0) return false;          // 32-bit dropout element index
+  return true;
+}
