@@ -140,6 +140,10 @@ constexpr int kGemmBatchMax = 3;
 struct GemmBatch { GemmP g[kGemmBatchMax]; int n; };
 int ocean_launch_gemm_batch(const GemmP* ps, int n, hipStream_t stream);
 
+// the kernel for outputs of few tiles (gemm_skinny.hip): ocean_launch_gemm_batch sends eligible batches there
+bool ocean_gemm_skinny_applies(const GemmBatch& b);
+int ocean_launch_gemm_skinny(const GemmBatch& b, hipStream_t stream);
+
 // optional kernel timing (prof.hip); token is null while profiling is off
 bool ocean_prof_on();
 void ocean_prof_begin(const char* name, double flops, double bytes, hipStream_t s, void** token);

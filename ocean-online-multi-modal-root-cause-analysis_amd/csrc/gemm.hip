@@ -167,12 +167,16 @@ __global__ __launch_bounds__(kThreads, 3) OCEAN_SINGLE_LDS_OPS void gemm_f32_ker
     t.kt = g_kt;
     t.valid = g_it < n_iter;
     ++g_it;
-    g_kk0 += BK;
     if (AKM) {
+      g_kk0 += BK;
       if (p.T > 0) { g_kt += BK; while (g_kt >= p.T) g_kt -= p.T; }
-    } else if (g_kk0 >= k_begin + nk * BK) {
-      g_kk0 = k_begin;
-      ++g_tap;
+    } else if (++g_tap >= p.taps) {
+      // taps innermost: the taps of one reduction tile read the same activation rows shifted by a few rows, so
+      // consecutive tiles of a block re-use lines that are still in L1 / L2 (with taps outermost a row came back
+      // only after a sweep over the whole reduction, by which time it had left the L2 of a busy chip: 1.8x the
+      // compulsory fetch on the 512-channel layers)
+      g_tap = 0;
+      g_kk0 += BK;
     }
     return t;
   };
@@ -630,13 +634,16 @@ int launch_cfg(const GemmBatch& b, bool aligned, hipStream_t stream) {
     if (AKM) zdim = p.taps * (p.split_k > 0 ? p.split_k : 1);
     flops += 2.0 * p.M * p.N * (double)p.K * p.taps;
     bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K * p.taps + (double)p.M * p.N * (AKM ? p.taps : 1));
+    if (!AKM && p.R != nullptr) bytes += 4.0 * (p.r_bcast_T > 0 ? (double)p.M / p.r_bcast_T : (double)p.M) * p.N;   // residual read
+    if (!AKM && p.bn_u != nullptr) bytes += 4.0 * (double)p.M * p.N;                                               // saved u read
   }
   dim3 grid(tiles, b.n, zdim);
   void* tok = nullptr;
   if (ocean_prof_on()) {
     char name[96];
-    snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%d,%d,%s,%s,%s>", BM, BN, BK, AKM ? "true" : "false", BKN ? "true" : "false",
-             aligned ? "true" : "false");
+    const bool bns = !AKM && BKN && b.g[0].bn_u != nullptr;
+    snprintf(name, sizeof(name), "gemm_f32_kernel<%d,%d,%d,%s,%s,%s%s>", BM, BN, BK, AKM ? "true" : "false", BKN ? "true" : "false",
+             aligned ? "true" : "false", bns ? ",bn-sums" : "");
     ocean_prof_begin(name, flops, bytes, stream, &tok);
   }
   static const int dyn_lds = [] { const char* e = getenv("OCEAN_GEMM_DYNLDS"); return e ? atoi(e) : 0; }();   // occupancy experiments
@@ -756,6 +763,7 @@ int ocean_launch_gemm_batch(const GemmP* ps, int n, hipStream_t stream) {
     b.g[q] = ps[q];
   }
   for (int q = n; q < kGemmBatchMax; ++q) b.g[q] = ps[0];
+  if (ocean_gemm_skinny_applies(b)) return ocean_launch_gemm_skinny(b, stream);
   if (ps[0].a_kmajor) return launch_mode<true, true>(b, aligned, stream);
   if (ps[0].b_kn) return launch_mode<false, true>(b, aligned, stream);
   return launch_mode<false, false>(b, aligned, stream);

@@ -1,0 +1,28 @@
+"""Which ATen operators (and how many device kernels) one eagerly launched update step still calls: everything the
+step does outside libocean_hip.so.  usage: python tools/aten_ops.py [BATCH]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ocean-online-multi-modal-root-cause-analysis_amd")); sys.path.insert(0, ROOT)
+import torch
+import bench
+import ocean
+from ocean.data import ServiceGraph
+from ocean.models.training import OnlineLearner
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+cfg = ocean.default_config(); cfg.model.num_services = 256
+torch.manual_seed(42)
+model = ocean.OCEANModel(cfg).cuda(); model.contrastive_negatives = "in_batch"
+learner = OnlineLearner(model, cfg)
+metrics, logs, nf, adj, labels = bench.synth_inputs(B, 128, 256, 256, 0, torch.device("cuda"))
+graph = ServiceGraph(adjacency_matrix=adj, node_features=nf)
+for _ in range(3):
+    learner.process_tensors(metrics, graph, logs, labels)
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    learner.process_tensors(metrics, graph, logs, labels)
+    torch.cuda.synchronize()
+rows = [(e.key, e.count, e.device_time_total) for e in prof.key_averages() if e.key.startswith("aten::") or "Backward" in e.key]
+rows.sort(key=lambda r: -r[1])
+for k, n, t in rows[:45]:
+    print(f"{n:4d}  {t:8.1f} us  {k}")

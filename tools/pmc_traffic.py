@@ -40,4 +40,17 @@ for r in rows[:40]:
     print(f"{r['kernel'][:60]:60s} grid {r['grid_threads']:>9d} x{r['launches']:<4d} fetch {r['fetch_bytes_per_launch'] / 1e6:9.1f} MB  "
           f"write {r['write_bytes_per_launch'] / 1e6:9.1f} MB")
 if len(sys.argv) > 3:
-    json.dump(rows, open(sys.argv[3], "w"), indent=1)
+    # bench.py quotes a figure from this file only when it was recorded with the kernel library and the bench script
+    # that are running: both hashes are stored with the rows
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def sha16(path):
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+    rec = {"lib_sha16": sha16(os.path.join(root, "ocean-online-multi-modal-root-cause-analysis_amd", "ocean", "libocean_hip.so")),
+           "bench_sha16": sha16(os.path.join(root, "bench.py")),
+           "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-graph",
+           "kernels": rows}
+    json.dump(rec, open(sys.argv[3], "w"), indent=1)
