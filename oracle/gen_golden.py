@@ -321,6 +321,7 @@ def gen_model():
                                 arrs["s0/cgrad/" + k] = p.grad.numpy().copy()       # clipped grads
                             else:
                                 arrs["s0/cgdig/" + k] = synth.digest(p.grad).numpy()
+                                arrs["s0/cgsamp/" + k] = synth.samples(p.grad).numpy()
                 opt.step()
                 if step in (0, 2):
                     for k, v in m.state_dict().items():
@@ -328,6 +329,8 @@ def gen_model():
                             arrs[pre + "sd_after/" + k] = v.numpy().copy()
                         else:
                             arrs[pre + "sddig_after/" + k] = synth.digest(v).numpy()
+                            if v.is_floating_point():
+                                arrs[pre + "sdsamp_after/" + k] = synth.samples(v).numpy()
                 arrs[pre + "bank"] = cm.memory_bank.numpy().copy()
                 arrs[pre + "ptr"] = cm.memory_ptr.numpy().copy()
             save(f"model_train_{tag}_{neg}", **arrs)

@@ -64,3 +64,20 @@ def digest(t: torch.Tensor, n: int = 16) -> torch.Tensor:
     samp = f[::stride][:n]
     pad = lambda x: torch.cat([x, torch.zeros(n - x.numel(), dtype=torch.double)])
     return torch.cat([torch.stack([f.sum(), f.norm(), f.abs().max()]), pad(head), pad(samp)]).float()
+
+
+def sample_positions(numel: int, n: int = 256) -> torch.Tensor:
+    """Up to n element positions spread over a tensor of `numel` elements: a fixed stride plus a half-stride offset,
+    so that a tensor's samples cover its whole range and differ from the positions `digest` looks at."""
+    if numel <= n:
+        return torch.arange(numel)
+    stride = numel // n
+    return (torch.arange(n) * stride + stride // 2).clamp_(max=numel - 1)
+
+
+def samples(t: torch.Tensor, n: int = 256) -> torch.Tensor:
+    """The values of `t` at sample_positions(t.numel(), n): what the default-architecture fixtures keep of every
+    gradient and post-step tensor for an ELEMENTWISE comparison (whole tensors of the 3.3 M-parameter model would
+    make the fixtures tens of megabytes)."""
+    f = t.detach().flatten()
+    return f[sample_positions(f.numel(), n)].clone()

@@ -27,6 +27,17 @@ def close(got, ref, tol):
     assert err <= tol * scale, f"max err {err:.3e} scale {scale:.3e}"
 
 
+def close_elem(got, ref, rel, floor, what=""):
+    """Every element on its own: |got - ref| <= rel * |ref| + floor (floor is an absolute amount)."""
+    got, ref = torch.as_tensor(got).detach().double().cpu().flatten(), torch.as_tensor(ref).detach().double().cpu().flatten()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if not ref.numel():
+        return
+    excess = (got - ref).abs() - (rel * ref.abs() + floor)
+    i = int(excess.argmax())
+    assert excess[i] <= 0, f"{what}: element {i}: got {got[i]:.6e} ref {ref[i]:.6e} (allowed {rel * abs(ref[i]) + floor:.3e})"
+
+
 def zero_dropout(model):
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
@@ -128,6 +139,10 @@ def run_steps(g, m, neg, tiny):
                     close(p.grad, g["s0/cgrad/" + k], 1e-3)
                 else:
                     close(synth.digest(p.grad.cpu()), g["s0/cgdig/" + k], 1e-3)
+                    # 256 evenly spaced elements of every gradient, each on its own: 1e-3 of the element plus 1e-5 of
+                    # the tensor's largest sampled magnitude (sums of ~1e3 fp32 terms in another order)
+                    ref = T(g["s0/cgsamp/" + k])
+                    close_elem(synth.samples(p.grad.cpu()), ref, 1e-3, 1e-5 * max(float(ref.abs().max()), 1e-6), "grad " + k)
         cm = m.fusion_module.contrastive_module
         close(cm.memory_bank, g[pre + "bank"], 1e-4)
         assert int(cm.memory_ptr) == int(g[pre + "ptr"][0])
@@ -137,6 +152,11 @@ def run_steps(g, m, neg, tiny):
                     close(v, g[pre + "sd_after/" + k], 5e-4)
                 else:
                     close(synth.digest(v.cpu()), g[pre + "sddig_after/" + k], 2e-3)
+                    if v.is_floating_point():
+                        # sampled elements of the state after the step.  Adam moves a weight by lr * m / (sqrt(v) + eps):
+                        # where the gradient is rounding noise around zero that quotient can take either sign, so
+                        # an element may be off by up to 2 * lr per step taken; everything else agrees to 1e-3
+                        close_elem(synth.samples(v.cpu()), T(g[pre + "sdsamp_after/" + k]), 1e-3, 2e-3 * (step + 1), "state " + k)
 
 
 @pytest.mark.parametrize("neg", ["bank", "in_batch"])

@@ -107,6 +107,9 @@ def run_steps(g, sd, arch, neg, tiny):
                     close(sd[k].grad, g["s0/cgrad/" + k], 1e-3)
                 else:
                     close(synth.digest(sd[k].grad), g["s0/cgdig/" + k], 1e-3)
+                    ref = T(g["s0/cgsamp/" + k])          # 256 evenly spaced elements, each on its own
+                    err = (synth.samples(sd[k].grad) - ref).abs()
+                    assert bool((err <= 1e-3 * ref.abs() + 1e-5 * max(float(ref.abs().max()), 1e-6)).all()), (k, float(err.max()))
         # the 12 dead q/k tensors have exactly-zero grads in the reference and
         # therefore still take Adam's coupled weight decay
         for k in tk:
@@ -125,6 +128,10 @@ def run_steps(g, sd, arch, neg, tiny):
                     # Adam turns fp32 noise on near-zero gradients into +-lr
                     # moves, so sums over big tensors only agree to ~1e-3
                     close(synth.digest(sd[k].detach()), g[pre + "sddig_after/" + k], 2e-3)
+                    if sd[k].is_floating_point():
+                        ref = T(g[pre + "sdsamp_after/" + k])
+                        err = (synth.samples(sd[k].detach()) - ref).abs()
+                        assert bool((err <= 1e-3 * ref.abs() + 2e-3 * (step + 1)).all()), (k, float(err.max()))
     return sd
 
 
