@@ -30,6 +30,7 @@ struct DcnnPlan {
   size_t h0, u[kMaxBN], a[kMaxBN], pooled;
   size_t stats[kMaxBN], fslots[kMaxBN], mean[kMaxBN], invstd[kMaxBN], scale[kMaxBN], shift[kMaxBN];
   size_t wp[OCEAN_MAX_CONV_LAYERS];
+  size_t wpT[OCEAN_MAX_CONV_LAYERS], wtT[OCEAN_MAX_CONV_LAYERS];   // transposed copies: block taps [Kt][Ci][Co], transitions [Ci][Co]
   size_t fwd_total;
   size_t gA, gB, dU, dpool, bstats[kMaxBN], bslots[kMaxBN], dwp[OCEAN_MAX_CONV_LAYERS], bwd_total;
 };
@@ -69,6 +70,8 @@ int make_plan(const ocean_dcnn_shape* s, DcnnPlan* p) {
   }
   for (int j = 0; j < p->nbn; ++j) p->fslots[j] = take(4 * (size_t)p->width[j] * kStatSlots);
   for (int i = 0; i < s->L; ++i) p->wp[i] = take((size_t)s->kernel_size * s->channels[i] * s->channels[i]);
+  for (int i = 0; i < s->L; ++i) p->wpT[i] = take((size_t)s->kernel_size * s->channels[i] * s->channels[i]);
+  for (int i = 0; i + 1 < s->L; ++i) p->wtT[i] = take((size_t)s->channels[i] * s->channels[i + 1]);
   p->fwd_total = o;
   o = 0;
   p->gA = take(M * p->cmax); p->gB = take(M * p->cmax); p->dU = take(M * p->cmax);
@@ -325,21 +328,28 @@ __global__ void bn_bwd_param_kernel(const double* __restrict__ bslots, double* _
   if (dgamma) dgamma[c] += (float)sx;
 }
 
-// Per-tap weight layouts of all convolution blocks in one launch (blockIdx.y = block):
-// w [Co][Ci][Kt] -> wp [Kt][Co][Ci] before the forward pass; dw [Co][Ci][Kt] += dwp [Kt][Co][Ci] after the backward pass.
-struct RepackSet { const float* src; float* dst; int Co, Ci; };
-struct RepackBatch { RepackSet s[OCEAN_MAX_CONV_LAYERS]; };
-__global__ void repack_w_kernel(const RepackBatch b, int Kt) {
+// Per-tap weight layouts of all convolution layers in one launch (blockIdx.y = set):
+// w [Co][Ci][Kt] -> wp [Kt][Co][Ci] (the forward product's [out][in] operand, and the data gradient's [k][n] operand) and
+// wpT [Kt][Ci][Co] (the data gradient's operand with the reduction index contiguous) before the forward pass;
+// dw [Co][Ci][Kt] += dwp [Kt][Co][Ci] after the backward pass.  A 1x1 transition is a set with Kt = 1 and no wp.
+struct RepackSet { const float* src; float* dst; float* dstT; int Co, Ci, Kt; };
+struct RepackBatch { RepackSet s[2 * OCEAN_MAX_CONV_LAYERS]; };
+__global__ void repack_w_kernel(const RepackBatch b) {
   const RepackSet r = b.s[blockIdx.y];
+  const int Kt = r.Kt;
   const long n = (long)r.Co * r.Ci * Kt;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int t = (int)(i % Kt);
     const long oc = i / Kt;          // co*Ci + ci
-    r.dst[(long)t * r.Co * r.Ci + oc] = r.src[i];
+    const float v = r.src[i];
+    if (r.dst) r.dst[(long)t * r.Co * r.Ci + oc] = v;
+    const long co = oc / r.Ci, ci = oc % r.Ci;
+    r.dstT[((long)t * r.Ci + ci) * r.Co + co] = v;
   }
 }
-__global__ void unpack_dw_kernel(const RepackBatch b, int Kt) {
+__global__ void unpack_dw_kernel(const RepackBatch b) {
   const RepackSet r = b.s[blockIdx.y];
+  const int Kt = r.Kt;
   const long n = (long)r.Co * r.Ci * Kt;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int t = (int)(i % Kt);
@@ -476,10 +486,14 @@ int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* para
       long biggest = 0;
       for (int i = 0; i < L; ++i) {
         const int C = s->channels[i];
-        rb.s[i] = RepackSet{params[pi_block(i, 0)], ws + pl.wp[i], C, C};
+        rb.s[i] = RepackSet{params[pi_block(i, 0)], ws + pl.wp[i], ws + pl.wpT[i], C, C, s->kernel_size};
         if ((long)C * C * s->kernel_size > biggest) biggest = (long)C * C * s->kernel_size;
       }
-      hipLaunchKernelGGL(repack_w_kernel, dim3(egrid(biggest), L), dim3(256), 0, st, rb, s->kernel_size);
+      for (int i = 0; i + 1 < L; ++i) {
+        rb.s[L + i] = RepackSet{params[pi_trans(L, i, 0)], nullptr, ws + pl.wtT[i], s->channels[i + 1], s->channels[i], 1};
+        if ((long)s->channels[i] * s->channels[i + 1] > biggest) biggest = (long)s->channels[i] * s->channels[i + 1];
+      }
+      hipLaunchKernelGGL(repack_w_kernel, dim3(egrid(biggest), 2 * L - 1), dim3(256), 0, st, rb);
       OCEAN_LAUNCH_CHECK();
       OCEAN_TRY(linear_fwd(x, s->F, params[0], params[1], ws + pl.h0, s->channels[0], pl.M, s->channels[0], s->F, 0, st));
       OCEAN_TRY(conv_fwd(pl, s, 0, ws + pl.h0, params, ws, ph + 1 >= phase_hi, st));
@@ -568,6 +582,8 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
     return true;
   };
 
+  auto nt_form = [](const GemmP& g) { GemmBatch b; b.n = 1; b.g[0] = g; return ocean_gemm_nt_applies(b); };
+
   for (int ph = phase_lo; ph < phase_hi; ++ph) {
     if (ph == 0) {
       OCEAN_TRY(zero_f32(wb + pl.bstats[0], pl.bwd_total - pl.bstats[0], st));   // bstats + packed weight grads
@@ -607,23 +623,39 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
       g.taps = k; g.tap_stride_c = (long)C * Cin;
       if (k > 1) { g.T = s->T; g.shift0 = -(k / 2) * d; g.shift_step = d; }
       OCEAN_TRY(ocean_launch_gemm(g, st));       // (the packed gradients of all blocks are unpacked together at the end)
-      // data gradient: taps with the opposite shift, plus the identity-residual gradient
+      // data gradient: taps with the opposite shift, plus the identity-residual gradient.  Preferred form: both operands
+      // with the reduction index (the output channels) contiguous, i.e. against the transposed weight copy; the
+      // [k][n] form serves the shapes that kernel does not take.
       GemmP h = gemm_defaults();
-      h.A = dU; h.lda = C; h.B = wf + pl.wp[i]; h.ldb = Cin; h.b_kn = 1; h.M = M; h.N = Cin; h.K = C;
+      h.A = dU; h.lda = C; h.M = M; h.N = Cin; h.K = C;
       if (k > 1) { h.taps = k; h.T = s->T; h.shift0 = (k / 2) * d; h.shift_step = -d; h.tap_stride_b = (long)C * Cin; }
       float* gout = grad_buf(j);          // same buffer: d(input) = conv^T(dU) + d(output)
       h.C = gout; h.ldc = Cin;
       if (last) { h.R = wb + pl.dpool; h.ldr = Cl; h.r_bcast_T = s->T; h.r_scale = 1.0f / (float)s->T; }
       else { h.R = gout; h.ldr = Cin; }
-      if (j > 0) rode = ride_along(h, j - 1);
+      h.B = wf + pl.wpT[i]; h.ldb = C; h.b_kn = 0;
+      bool nt = false;
+      if (j > 0) { GemmP t = h; if (ride_along(t, j - 1)) { h = t; rode = nt = true; } }
+      if (!nt) nt = nt_form(h);
+      if (!nt) {
+        h.B = wf + pl.wp[i]; h.ldb = Cin; h.b_kn = 1;
+        if (j > 0) rode = ride_along(h, j - 1);
+      }
       OCEAN_TRY(ocean_launch_gemm(h, st));
     } else {
       const int i = pl.li[j];
       OCEAN_TRY(linear_bwd_weight(dU, C, in, Cin, grads[pi_trans(L, i, 0)], M, C, Cin, st));
-      GemmP h = gemm_defaults();        // dx = dU . W   (W [C, Cin] read as [k][n])
-      h.A = dU; h.lda = C; h.B = params[pi_trans(L, i, 0)]; h.ldb = Cin; h.b_kn = 1; h.C = grad_buf(j - 1); h.ldc = Cin;
+      GemmP h = gemm_defaults();        // dx = dU . W: against the transposed copy [Cin][C] when that kernel takes the shape, else W [C, Cin] read as [k][n]
+      h.A = dU; h.lda = C; h.C = grad_buf(j - 1); h.ldc = Cin;
       h.M = M; h.N = Cin; h.K = C;
-      rode = ride_along(h, j - 1);
+      h.B = wf + pl.wtT[i]; h.ldb = C; h.b_kn = 0;
+      bool nt = false;
+      { GemmP t = h; if (ride_along(t, j - 1)) { h = t; rode = nt = true; } }
+      if (!nt) nt = nt_form(h);
+      if (!nt) {
+        h.B = params[pi_trans(L, i, 0)]; h.ldb = Cin; h.b_kn = 1;
+        rode = ride_along(h, j - 1);
+      }
       OCEAN_TRY(ocean_launch_gemm(h, st));
     }
     if (j > 0) {
@@ -640,10 +672,10 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
       long biggest = 0;
       for (int i = 0; i < L; ++i) {
         const int Cb = s->channels[i];
-        rb.s[i] = RepackSet{wb + pl.dwp[i], grads[pi_block(i, 0)], Cb, Cb};
+        rb.s[i] = RepackSet{wb + pl.dwp[i], grads[pi_block(i, 0)], nullptr, Cb, Cb, s->kernel_size};
         if ((long)Cb * Cb * s->kernel_size > biggest) biggest = (long)Cb * Cb * s->kernel_size;
       }
-      hipLaunchKernelGGL(unpack_dw_kernel, dim3(egrid(biggest), L), dim3(256), 0, st, rb, s->kernel_size);
+      hipLaunchKernelGGL(unpack_dw_kernel, dim3(egrid(biggest), L), dim3(256), 0, st, rb);
       OCEAN_LAUNCH_CHECK();
     }
   }

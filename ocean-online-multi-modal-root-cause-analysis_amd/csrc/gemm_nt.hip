@@ -1,0 +1,267 @@
+// fp32 GEMM for the large products whose operands are both stored with the reduction index contiguous
+// (activations [rows][channels] times weights [out][in]: the convolutions' forward and, against a transposed copy of
+// the weights, their data gradients).
+//
+// What differs from the general kernel of gemm.hip:
+//  * operand tiles keep their k-contiguous storage in LDS (64-byte rows of 16 k-values, the four 16-byte quads of a
+//    row XOR-swizzled by (row >> 2) & 3), so a staged float4 is written with one ds_write_b128 and lane (m, h) reads
+//    the four values k = 8q + 4h .. + 3 of row m with one ds_read_b128: MFMA t of a group then multiplies k = 8q + t
+//    (lanes h = 0) and k = 8q + 4 + t (h = 1) on both operands alike.  8 fragment reads and 4 staging writes per 16-deep
+//    tile where the k-major layout needs 32 and 10-16;
+//  * a dilated convolution's three taps read ONE staged window of rows: a tile of 128 rows is one sample (T == 128),
+//    its rows sit in LDS between two bands of zero rows (the convolution's padding), and tap t reads the fragments
+//    `shift_t` rows up or down.  The activation tile is loaded and stored once per 16 channels instead of once per tap.
+// Tiles are always full (the host sends only such problems here), so there is no bounds test anywhere.
+#include "gemm_epilogue.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kPad = 32;                 // zero rows on either side of the window = largest row shift served
+
+// byte offset of 16-byte quad `kq` of row `r` inside a tile image
+__device__ __forceinline__ unsigned img_off(int r, int kq) { return (unsigned)r * 64u + (unsigned)((kq ^ ((r >> 2) & 3)) << 4); }
+
+template <int BN, int TAPS, bool BNS>
+__global__ __launch_bounds__(kThreads, 3) void gemm_nt_kernel(const GemmBatch batch) {
+  const GemmP& p = batch.g[blockIdx.y];
+  constexpr int BM = 128, BK = 16;
+  constexpr int TM = 2, TN = BN / 64;
+  constexpr int A_SLOTS = TAPS == 3 ? 2 : 3, B_SLOTS = 3;
+  constexpr int A_ROWS = BM + (TAPS == 3 ? 2 * kPad : 0);
+  constexpr int A_SLOT_BYTES = A_ROWS * 64, B_SLOT_BYTES = BN * 64;
+  constexpr int A_PIECES = 2, B_PIECES = BN / 64;           // float4 per thread per tile
+  __shared__ __align__(16) char smem[A_SLOTS * A_SLOT_BYTES + B_SLOTS * B_SLOT_BYTES];
+  char* const As = smem;
+  char* const Bs = smem + A_SLOTS * A_SLOT_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lm = lane & 31, h = lane >> 5;
+
+  const int tiles_n = p.N / BN, tiles_m = p.M / BM;
+  const int nwg = tiles_m * tiles_n;
+  if ((int)blockIdx.x >= nwg) return;
+  const int bid = xcd_swizzle(blockIdx.x, nwg);
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int n_chunks = p.K / BK;
+  const int n_iter = TAPS * n_chunks;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, 0x7FFFFFF0, 0x00020000);
+  constexpr unsigned kOob = 0x80000000u;
+  auto buf_load = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, int soff) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, soff, 0);
+    const unsigned x = r[0], y = r[1], z = r[2], w = r[3];
+    return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
+  };
+
+  // staging coordinates: piece i of a tile is quad (idx & 3) of row (idx >> 2), idx = tid + 256 i
+  unsigned a_goff[A_PIECES], a_loff[A_PIECES], b_goff[B_PIECES], b_loff[B_PIECES];
+#pragma unroll
+  for (int i = 0; i < A_PIECES; ++i) {
+    const int idx = tid + i * kThreads, row = idx >> 2, kq = idx & 3;
+    a_goff[i] = (unsigned)((m0 + row) * p.lda + kq * 4) * 4u;
+    a_loff[i] = img_off(row + (TAPS == 3 ? kPad : 0), kq);
+  }
+#pragma unroll
+  for (int i = 0; i < B_PIECES; ++i) {
+    const int idx = tid + i * kThreads, row = idx >> 2, kq = idx & 3;
+    b_goff[i] = (unsigned)((n0 + row) * p.ldb + kq * 4) * 4u;
+    b_loff[i] = img_off(row, kq);
+  }
+  float4 ra[A_PIECES], rb[B_PIECES];
+  auto load_a = [&](int chunk) {      // activation rows of reduction chunk `chunk` (zeros past the end)
+    const bool ok = chunk < n_chunks;
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) ra[i] = buf_load(rsrc_a, ok ? a_goff[i] : kOob, chunk * (BK * 4));
+  };
+  auto load_b = [&](int tap, int chunk) {
+    const bool ok = chunk < n_chunks;
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) rb[i] = buf_load(rsrc_b, ok ? b_goff[i] : kOob, (int)(tap * p.tap_stride_b + chunk * BK) * 4);
+  };
+  auto store_a = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) *reinterpret_cast<float4*>(As + slot * A_SLOT_BYTES + a_loff[i]) = ra[i];
+  };
+  auto store_b = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) *reinterpret_cast<float4*>(Bs + slot * B_SLOT_BYTES + b_loff[i]) = rb[i];
+  };
+
+  // fragment addresses: this lane's row of sub-tile 0 (sub-tile 1 is 32 rows = 2048 bytes further, same swizzle), one
+  // address per 8-deep half q of a tile and, for the window, per tap
+  unsigned a_rd[TAPS][2], b_rd[2];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const int shift = TAPS == 3 ? p.shift0 + t * p.shift_step : 0;
+    const int r = wm * 64 + lm + (TAPS == 3 ? kPad + shift : 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) a_rd[t][q] = img_off(r, 2 * q + h);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) b_rd[q] = img_off(wn * (BN / 2) + lm, 2 * q + h);
+
+  if (TAPS == 3) {
+    // the zero bands of both window slots: rows [0, kPad) and [kPad + BM, A_ROWS), never written again
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int idx = tid; idx < 2 * kPad * 4 * A_SLOTS; idx += kThreads) {
+      const int slot = idx / (2 * kPad * 4), w = idx % (2 * kPad * 4);
+      const int r = (w >> 2) < kPad ? (w >> 2) : (w >> 2) + BM;
+      *reinterpret_cast<float4*>(As + slot * A_SLOT_BYTES + r * 64 + (w & 3) * 16) = z;
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: tile 0 into slot 0, tile 1's operands into the registers
+  load_a(0);
+  load_b(0, 0);
+  store_a(0);
+  store_b(0);
+  if (TAPS == 3) load_b(1, 0);
+  else { load_a(1); load_b(0, 1); }
+  __syncthreads();
+
+  float4 fa[2][TM], fb[2][TN];         // fragments of the two halves of a tile
+  auto read_frags = [&](int half, int a_slot, int b_slot, int tap, int q) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[half][i] = *reinterpret_cast<const float4*>(As + a_slot * A_SLOT_BYTES + a_rd[tap][q] + i * 2048);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[half][j] = *reinterpret_cast<const float4*>(Bs + b_slot * B_SLOT_BYTES + b_rd[q] + j * 2048);
+  };
+  auto mfma_group = [&](int half, int t) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float av = t == 0 ? fa[half][i].x : t == 1 ? fa[half][i].y : t == 2 ? fa[half][i].z : fa[half][i].w;
+        const float bv = t == 0 ? fb[half][j].x : t == 1 ? fb[half][j].y : t == 2 ? fb[half][j].z : fb[half][j].w;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+      }
+  };
+  read_frags(0, 0, 0, 0, 0);
+
+  // One 16-deep tile = two halves of 4 MFMA groups.  During the first half the registers holding tile it+1 go to
+  // their ring slots and are reloaded with tile it+2; the barrier sits between the halves; the second half starts by
+  // reading the first fragments of tile it+1.  With three taps the activation registers move only once per chunk:
+  // loaded during tap 1, stored during tap 2 (into the other window slot, last read two barriers ago).
+  int chunk = 0;
+  auto tile_step = [&](auto tap_c, auto aslot_c, auto bslot_c, const int it) {
+    constexpr int TAP = decltype(tap_c)::value, ASLOT = decltype(aslot_c)::value, BSLOT = decltype(bslot_c)::value;
+    constexpr int NB = (BSLOT + 1) % B_SLOTS;
+    constexpr bool NEXT_CHUNK = TAPS == 1 || TAP == 2;              // tile it+1 starts a new reduction chunk
+    constexpr int NA = NEXT_CHUNK ? (ASLOT + 1) % A_SLOTS : ASLOT;
+    constexpr int NTAP = TAPS == 1 ? 0 : (TAP + 1) % 3;
+    const bool more = it + 1 < n_iter;
+    read_frags(1, ASLOT, BSLOT, TAP, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(0, 0);
+    // tile it+1's weights -> ring, tile it+2's weights -> registers
+    store_b(NB);
+    if (TAPS == 3) load_b((TAP + 2) % 3, chunk + (TAP + 2) / 3);
+    else load_b(0, chunk + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(0, 1);
+    if (TAPS == 1) { store_a(NA); load_a(chunk + 2); }
+    else if (TAP == 2) store_a(NA);
+    else if (TAP == 1) load_a(chunk + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(0, 2);
+    mfma_group(0, 3);
+    __syncthreads();
+    if (more) read_frags(0, NA, NB, NTAP, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(1, 0);
+    mfma_group(1, 1);
+    mfma_group(1, 2);
+    mfma_group(1, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (NEXT_CHUNK) ++chunk;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  int it = 0;
+  if (TAPS == 3) {
+    for (; it + 6 <= n_iter; it += 6) {
+      tile_step(I0{}, I0{}, I0{}, it);     tile_step(I1{}, I0{}, I1{}, it + 1); tile_step(I2{}, I0{}, I2{}, it + 2);
+      tile_step(I0{}, I1{}, I0{}, it + 3); tile_step(I1{}, I1{}, I1{}, it + 4); tile_step(I2{}, I1{}, I2{}, it + 5);
+    }
+    if (it < n_iter) {                     // an odd number of chunks: one more, in window slot 0
+      tile_step(I0{}, I0{}, I0{}, it); tile_step(I1{}, I0{}, I1{}, it + 1); tile_step(I2{}, I0{}, I2{}, it + 2);
+    }
+  } else {
+    for (; it + 3 <= n_iter; it += 3) {
+      tile_step(I0{}, I0{}, I0{}, it); tile_step(I0{}, I1{}, I1{}, it + 1); tile_step(I0{}, I2{}, I2{}, it + 2);
+    }
+    if (it < n_iter) {
+      tile_step(I0{}, I0{}, I0{}, it);
+      if (it + 1 < n_iter) tile_step(I0{}, I1{}, I1{}, it + 1);
+    }
+  }
+
+  const EpiArgs e = make_epi_args(p);
+  const DropoutP bn_drop = BNS ? dropout_resolve(p.bn_drop) : DropoutP{0.f, 0, nullptr};
+  epilogue_full<BM, BN, false, BNS>(acc, e, e.C, bn_drop, m0, n0, tile_m, wave, lane);
+}
+
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+template <int BN, int TAPS>
+void launch_nt(const GemmBatch& b, dim3 grid, hipStream_t stream) {
+  if (b.g[0].bn_u != nullptr) hipLaunchKernelGGL((gemm_nt_kernel<BN, TAPS, true>), grid, dim3(kThreads), 0, stream, b);
+  else hipLaunchKernelGGL((gemm_nt_kernel<BN, TAPS, false>), grid, dim3(kThreads), 0, stream, b);
+}
+
+}  // namespace
+
+// One problem, both operands k-contiguous, every tile full, enough tiles to fill the chip; a three-tap problem must have
+// one sample per row tile and symmetric shifts within the zero bands.
+bool ocean_gemm_nt_applies(const GemmBatch& b) {
+  static const bool off = getenv("OCEAN_GEMM_NO_NT") != nullptr;          // measurement switch
+  if (off || b.n != 1) return false;
+  const GemmP& p = b.g[0];
+  if (p.a_kmajor || p.b_kn || (p.taps != 1 && p.taps != 3)) return false;
+  if (p.M % 128 != 0 || p.N % 64 != 0 || p.K % 16 != 0 || p.K < 32) return false;
+  if ((long)(p.M / 128) * (p.N % 128 == 0 ? p.N / 128 : p.N / 64) < 256) return false;
+  if (!al16(p.A) || !al16(p.B) || p.lda % 4 != 0 || p.ldb % 4 != 0 || p.tap_stride_b % 4 != 0) return false;
+  if ((double)p.M * p.lda >= 5.0e8 || (double)p.N * p.ldb + (double)(p.taps - 1) * (double)p.tap_stride_b >= 5.0e8) return false;
+  if (p.taps == 3) {
+    if (p.T != 128 || p.shift_step != -p.shift0 || p.shift0 > kPad || p.shift0 < -kPad) return false;
+  }
+  if (p.drop.p > 0.f || p.relu_mask != nullptr || p.a_colsum != nullptr) return false;
+  if (p.r_bcast_T > 0 && (p.bn_u == nullptr || p.R == nullptr || p.r_bcast_T % 128 != 0)) return false;
+  if (p.bn_u != nullptr && (p.bias != nullptr || (double)p.M * (double)p.N >= 4294967296.0)) return false;
+  return true;
+}
+
+int ocean_launch_gemm_nt(const GemmBatch& b, hipStream_t stream) {
+  const GemmP& p = b.g[0];
+  const int bn = p.N % 128 == 0 ? 128 : 64;
+  const dim3 grid((p.M / 128) * (p.N / bn), 1, 1);
+  void* tok = nullptr;
+  if (ocean_prof_on()) {
+    char name[96];
+    snprintf(name, sizeof(name), "gemm_nt_kernel<%d,%d%s>", bn, p.taps, p.bn_u != nullptr ? ",bn-sums" : "");
+    double bytes = 4.0 * ((double)p.M * p.K + (double)p.N * p.K * p.taps + (double)p.M * p.N);
+    if (p.R != nullptr) bytes += 4.0 * (p.r_bcast_T > 0 ? (double)p.M / p.r_bcast_T : (double)p.M) * p.N;
+    if (p.bn_u != nullptr) bytes += 4.0 * (double)p.M * p.N;
+    ocean_prof_begin(name, 2.0 * p.M * p.N * (double)p.K * p.taps, bytes, stream, &tok);
+  }
+  if (bn == 128) { if (p.taps == 3) launch_nt<128, 3>(b, grid, stream); else launch_nt<128, 1>(b, grid, stream); }
+  else { if (p.taps == 3) launch_nt<64, 3>(b, grid, stream); else launch_nt<64, 1>(b, grid, stream); }
+  ocean_prof_end(tok, stream);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}

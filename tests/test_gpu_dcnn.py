@@ -75,7 +75,11 @@ def test_default_architecture_fixture(golden):
 
 @pytest.mark.parametrize("B,T_,ch,dil,k", [(4, 33, [16, 32], [1, 2], 3), (2, 64, [64, 128, 256, 512], [1, 2, 4, 8], 3),
                                             (3, 5, [12, 20], [2, 4], 5), (1, 2, [8], [1], 3), (5, 9, [6, 10], [1, 3], 1),
-                                            (3, 50, [7, 13], [1, 2], 3), (2, 300, [1028], [2], 3)])
+                                            (3, 50, [7, 13], [1, 2], 3), (2, 300, [1028], [2], 3),
+                                            # one sample per 128-row tile and at least 256 tiles: the window kernel serves the
+                                            # forward convolutions and, against transposed weights, the data gradients (with the
+                                            # BatchNorm sums in the epilogue); dilation 40 is beyond its zero bands
+                                            (256, 128, [64, 128], [3, 32], 3), (256, 128, [64], [40], 3)])
 def test_against_oracle_random(B, T_, ch, dil, k):
     from ocean.models.components import DilatedCNN
     torch.manual_seed(0)

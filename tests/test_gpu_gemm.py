@@ -88,3 +88,45 @@ def test_bad_arguments_are_rejected():
         _hip.gemm(t, t, t, 0, 4, 4)
     with pytest.raises(_hip.OceanHipError):
         _hip.gemm(torch.zeros(4, 4), t, t, 4, 4, 4)        # CPU tensor: no fallback
+
+
+# Shapes that take the k-contiguous-operand kernel (full 128-row tiles, at least 256 of them): plain products ...
+@pytest.mark.parametrize("M,N,K", [(32768, 128, 64), (32768, 64, 192), (16384, 512, 48), (32768, 128, 32), (65536, 64, 80)])
+def test_large_full_tile_products(M, N, K):
+    from ocean import _hip
+    a, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2), _rand(N, seed=3)
+    r = _rand(M, N, seed=4)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    _hip.gemm(a.cuda(), w.cuda(), out, M, N, K, bias=b.cuda(), residual=r.cuda(), relu=True)
+    _close(out, torch.relu(a.double() @ w.double().t() + b.double() + r.double()))
+
+
+# ... and three-tap dilated convolutions whose row tile is one sample (T = 128): the taps read one staged window of
+# rows between zero bands; shifts up to 32 rows, either sign order (forward and data-gradient orientation), and a
+# dilation beyond the bands (falls back to the general kernel).
+@pytest.mark.parametrize("B,Cin,Cout,d,flip", [(256, 64, 128, 1, False), (256, 64, 64, 8, False), (256, 48, 128, 32, True),
+                                               (256, 128, 64, 5, True), (128, 32, 256, 2, False), (256, 64, 128, 40, False),
+                                               (256, 16, 128, 3, False)])
+def test_dilated_conv_window(B, Cin, Cout, d, flip):
+    from ocean import _hip
+    T = 128
+    M = B * T
+    x, w = _rand(M, Cin, seed=1), _rand(3, Cout, Cin, seed=2) * 0.1
+    xd, wd = x.cuda(), w.cuda()
+    out = torch.full((M, Cout), float("nan"), device="cuda")
+    s0, st = (d, -d) if flip else (-d, d)
+    rc = _hip.lib().ocean_conv_gemm_f32(xd.data_ptr(), Cin, wd.data_ptr(), Cin, out.data_ptr(), Cout, M, Cout, Cin, 0, 0, 3, T, s0, st,
+                                        Cout * Cin, 0, 1, _hip.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    xs = x.double().view(B, T, Cin)
+    ref = torch.zeros(B, T, Cout, dtype=torch.float64)
+    for t in range(3):
+        s = s0 + t * st
+        sh = torch.zeros_like(xs)
+        if s >= 0:
+            sh[:, :T - s] = xs[:, s:]
+        else:
+            sh[:, -s:] = xs[:, :T + s]
+        ref += sh @ w[t].double().t()
+    _close(out, ref.view(M, Cout))
