@@ -61,34 +61,89 @@ __device__ __forceinline__ void epilogue_full(f32x16 (&acc)[TM][TN], const EpiAr
   const char* u_w = (const char*)(bn_on ? e.bn_u + (long)row_w * e.ld_bn_u + col_w : e.C);
   const uint32_t u_lane = ((uint32_t)(4 * khalf) * (uint32_t)e.ld_bn_u + lcol) * 4u, u_pitch = (uint32_t)e.ld_bn_u * 4u;
   const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(u_w), 0, 0x7FFFFFF0, 0x00020000);
+  if constexpr (bn_on) {
+    // With the BatchNorm sums riding along every output element needs its saved u (and its residual) from memory.
+    // The elements go in groups of eight, and the loads of group g+1 are issued before group g is worked on, so
+    // the block waits for memory once, not once per group; the per-column constants of all column groups are
+    // fetched up front for the same reason.  (By now the main loop's staging and fragment registers are free.)
+    constexpr int G = 8, GPS = 16 / G, NG = TN * TM * GPS;
+    const bool bcast_r = has_r && e.r_bcast_T > 0;
+    float sc_[TN], sh_[TN], mu_[TN], is_[TN], rb_[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col_u = col_w + j * 32;
-    if (e.colstats != nullptr) {
-      float s = 0.f, q = 0.f;
+    for (int j = 0; j < TN; ++j) {
+      const int c = col_w + j * 32 + lcol;
+      sc_[j] = e.bn_scale[c]; sh_[j] = e.bn_shift[c]; mu_[j] = e.bn_mean[c]; is_[j] = e.bn_invstd[c];
+      // residual broadcast from one row per sample: the host sends such a launch here only when a tile lies inside one
+      // sample (T % BM == 0), so the row is block-uniform and the value depends on the column alone
+      rb_[j] = bcast_r ? e.r_scale * e.R[(long)(m0 / e.r_bcast_T) * e.ldr + c] : 0.f;
+    }
+    float rv[2][G], uv[2][G];
+    auto issue = [&](const int gi, const int buf) {
+      const int j = gi / (TM * GPS), i = (gi / GPS) % TM, r0 = (gi % GPS) * G;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int x = 0; x < G; ++x) {
+        const int r = r0 + x;
+        const uint32_t roff = (uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3));
+        rv[buf][x] = bcast_r ? rb_[j] : (has_r ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)r_lane, (int)(roff * r_pitch + (uint32_t)(j * 128)), 0)) : 0.f);
+        uv[buf][x] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_u, (int)u_lane, (int)(roff * u_pitch + (uint32_t)(j * 128)), 0));
+      }
+    };
+    float bn_sg = 0.f, bn_sx = 0.f;
+    issue(0, 0);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s += v; q += v * v; }
-      s += __shfl_xor(s, 32);
-      q += __shfl_xor(q, 32);
-      if (lane < 32) {
-        double* cs = e.colstats + (size_t)(tile_m % e.colstat_slots) * 2 * e.N + col_u;
-        unsafeAtomicAdd(cs + lcol, (double)s);
-        unsafeAtomicAdd(cs + e.N + lcol, (double)q);
+    for (int gi = 0; gi < NG; ++gi) {
+      const int buf = gi & 1;
+      const int j = gi / (TM * GPS), i = (gi / GPS) % TM, r0 = (gi % GPS) * G;
+      if (gi + 1 < NG) issue(gi + 1, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const uint32_t bn_idx_lane = 4u * (uint32_t)khalf * (uint32_t)e.N + (uint32_t)(col_w + j * 32 + lcol);
+#pragma unroll
+      for (int x = 0; x < G; ++x) {
+        const int r = r0 + x;
+        const uint32_t roff = (uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3));
+        const float out = fmaxf(acc[i][j][r] + rv[buf][x], floor_v);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out), rs_c, (int)c_lane, (int)(roff * c_pitch + (uint32_t)(j * 128)), 0);
+        float g = (fmaf(uv[buf][x], sc_[j], sh_[j]) > 0.f) ? out : 0.f;
+        if (bn_drop.p > 0.f) {
+          // element index row * N + col; the host sends a launch here only when M * N < 2^32
+          g *= dropout_keep_lo(bn_drop, ((uint32_t)row_w + roff) * (uint32_t)e.N + bn_idx_lane);
+        }
+        bn_sg += g;
+        bn_sx += g * (uv[buf][x] - mu_[j]) * is_[j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if ((gi + 1) % (TM * GPS) == 0) {        // column group j is complete
+        bn_sg += __shfl_xor(bn_sg, 32);
+        bn_sx += __shfl_xor(bn_sx, 32);
+        if (lane < 32) {
+          double* bs = e.bn_slots + (size_t)(tile_m % e.bn_nslots) * 2 * e.N + col_w + j * 32;
+          unsafeAtomicAdd(bs + lcol, (double)bn_sg);
+          unsafeAtomicAdd(bs + e.N + lcol, (double)bn_sx);
+        }
+        bn_sg = 0.f; bn_sx = 0.f;
       }
     }
-    const float bias = e.bias != nullptr ? e.bias[col_u + lcol] : 0.f;
-    float bn_sc = 0.f, bn_sh = 0.f, bn_mu = 0.f, bn_is = 0.f, bn_sg = 0.f, bn_sx = 0.f;
-    if (bn_on) { bn_sc = e.bn_scale[col_u + lcol]; bn_sh = e.bn_shift[col_u + lcol]; bn_mu = e.bn_mean[col_u + lcol]; bn_is = e.bn_invstd[col_u + lcol]; }
-    const uint32_t bn_idx_lane = 4u * (uint32_t)khalf * (uint32_t)e.N + (uint32_t)(col_u + lcol);
-    // residual broadcast from one row per sample: the host sends such a launch here only when a tile lies inside one
-    // sample (T % BM == 0), so the row is block-uniform and the value depends on the column alone
-    const bool bcast_r = bn_on && has_r && e.r_bcast_T > 0;
-    const float rb_val = bcast_r ? e.r_scale * e.R[(long)(m0 / e.r_bcast_T) * e.ldr + col_u + lcol] : 0.f;
+  } else {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      if constexpr (!bn_on) {
+    for (int j = 0; j < TN; ++j) {
+      const int col_u = col_w + j * 32;
+      if (e.colstats != nullptr) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s += v; q += v * v; }
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (lane < 32) {
+          double* cs = e.colstats + (size_t)(tile_m % e.colstat_slots) * 2 * e.N + col_u;
+          unsafeAtomicAdd(cs + lcol, (double)s);
+          unsafeAtomicAdd(cs + e.N + lcol, (double)q);
+        }
+      }
+      const float bias = e.bias != nullptr ? e.bias[col_u + lcol] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
         // the sixteen residual values of a 32x32 sub-tile are requested together: one memory round trip, not four
         float rv[16];
 #pragma unroll
@@ -106,45 +161,6 @@ __device__ __forceinline__ void epilogue_full(f32x16 (&acc)[TM][TN], const EpiAr
           if (atomic_out) unsafeAtomicAdd((float*)(c_w + (size_t)c_soff + c_lane), v);
           else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaxf(v + rv[r], floor_v)), rs_c, (int)c_lane, (int)c_soff, 0);
         }
-      } else {
-        // with the BatchNorm sums riding along: four values at a time (residual and saved u of the same elements), so
-        // that the live registers stay within what the main loop needs anyway
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          float rv[4], uv[4];
-#pragma unroll
-          for (int r8 = 0; r8 < 4; ++r8) {
-            const int r = rq * 4 + r8;
-            const uint32_t roff = (uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3));
-            rv[r8] = bcast_r ? rb_val : (has_r ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)r_lane, (int)(roff * r_pitch + (uint32_t)(j * 128)), 0)) : 0.f);
-            uv[r8] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_u, (int)u_lane, (int)(roff * u_pitch + (uint32_t)(j * 128)), 0));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int r8 = 0; r8 < 4; ++r8) {
-            const int r = rq * 4 + r8;
-            const uint32_t roff = (uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3));
-            const float out = fmaxf(acc[i][j][r] + bias + rv[r8], floor_v);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out), rs_c, (int)c_lane, (int)(roff * c_pitch + (uint32_t)(j * 128)), 0);
-            float g = (fmaf(uv[r8], bn_sc, bn_sh) > 0.f) ? out : 0.f;
-            if (bn_drop.p > 0.f) {
-              // element index row * N + col; the host sends a launch here only when M * N < 2^32
-              g *= dropout_keep_lo(bn_drop, ((uint32_t)row_w + roff) * (uint32_t)e.N + bn_idx_lane);
-            }
-            bn_sg += g;
-            bn_sx += g * (uv[r8] - bn_mu) * bn_is;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    if (bn_on) {
-      bn_sg += __shfl_xor(bn_sg, 32);
-      bn_sx += __shfl_xor(bn_sx, 32);
-      if (lane < 32) {
-        double* bs = e.bn_slots + (size_t)(tile_m % e.bn_nslots) * 2 * e.N + col_u;
-        unsafeAtomicAdd(bs + lcol, (double)bn_sg);
-        unsafeAtomicAdd(bs + e.N + lcol, (double)bn_sx);
       }
     }
   }

@@ -117,15 +117,117 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmBatch b
   }
 }
 
+// Row reductions with a small output (a linear layer's weight gradient C[M][N] += sum_k A[k][m] B[k][n] over a few
+// thousand rows, optionally the column sums of A on the side: its bias gradient).  Such a launch is bound by memory
+// round trips and by the cost of atomic adds, not by arithmetic.  A block of SIXTEEN waves owns one 32x32 output tile
+// and splits the rows sixteen ways, so a wave's share is a few dozen rows whose loads it can request all at once; both
+// operands are row-major over the reduction index, so lane (c, h) loads element c of row k = 2s + h of either operand
+// straight into its MFMA register (32 consecutive floats of a row per half-wave).  The sixteen partial tiles meet in
+// LDS, one thread per output element.  With one block per tile (the usual case) and no other problem of the batch writing
+// the same matrix, the block is the tile's only writer and adds it into C with plain loads and stores; only outputs of very few tiles split the rows over blocks as well
+// (grid.z) and then add atomically (measured: 8 slices adding into 3 x 128 x 768 outputs took 48 us, the atomics alone).
+constexpr int kRowsWaves = 16;
+constexpr int kRedUnroll = 8;          // MFMA steps whose 2 x 8 loads are requested together (two such groups in flight; 12 would spill at 16 waves per block)
+
+__global__ __launch_bounds__(kRowsWaves * 64) void gemm_skinny_rows_kernel(const GemmBatch batch, const int plain) {
+  const GemmP& p = batch.g[blockIdx.y];
+  const int tiles_n = (p.N + 31) / 32, tiles_m = (p.M + 31) / 32;
+  if ((int)blockIdx.x >= tiles_m * tiles_n) return;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int m0 = tile_m * 32, n0 = tile_n * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 31, h = lane >> 5;
+
+  // rows of this block's slice, then of this wave's share of it (whole MFMA steps of two rows)
+  const int steps = (p.K + 1) / 2;
+  const int per_block = (steps + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int b_begin = (int)blockIdx.z * per_block, b_end = min(steps, b_begin + per_block);
+  const int per_wave = (per_block + kRowsWaves - 1) / kRowsWaves;
+  const int s_begin = b_begin + wave * per_wave, s_end = min(b_end, s_begin + per_wave);
+
+  constexpr unsigned kOob = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, 0x7FFFFFF0, 0x00020000);
+  const bool a_ok = m0 + lm < p.M, b_ok = n0 + lm < p.N;
+  const unsigned a_base = (unsigned)(h * p.lda + m0 + lm) * 4u, b_base = (unsigned)(h * p.ldb + n0 + lm) * 4u;
+  const unsigned a_step = (unsigned)p.lda * 8u, b_step = (unsigned)p.ldb * 8u;      // two rows
+  auto load_step = [&](int s, float& a, float& b) {
+    const bool k_ok = s < s_end && 2 * s + h < p.K;
+    a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_a, (int)((a_ok && k_ok) ? a_base + (unsigned)s * a_step : kOob), 0, 0));
+    b = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc_b, (int)((b_ok && k_ok) ? b_base + (unsigned)s * b_step : kOob), 0, 0));
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float asum = 0.f;
+  // two groups of kRedUnroll steps per trip, each group's loads requested while the other group is multiplied
+  float a0[kRedUnroll], b0[kRedUnroll], a1[kRedUnroll], b1[kRedUnroll];
+#pragma unroll
+  for (int u = 0; u < kRedUnroll; ++u) load_step(s_begin + u, a0[u], b0[u]);
+  for (int s = s_begin; s < s_end; s += 2 * kRedUnroll) {
+#pragma unroll
+    for (int u = 0; u < kRedUnroll; ++u) load_step(s + kRedUnroll + u, a1[u], b1[u]);
+#pragma unroll
+    for (int u = 0; u < kRedUnroll; ++u) { asum += a0[u]; acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc, 0, 0, 0); }
+#pragma unroll
+    for (int u = 0; u < kRedUnroll; ++u) load_step(s + 2 * kRedUnroll + u, a0[u], b0[u]);
+#pragma unroll
+    for (int u = 0; u < kRedUnroll; ++u) { asum += a1[u]; acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0); }
+  }
+
+  __shared__ float part[kRowsWaves][32][33];
+  __shared__ float csum[kRowsWaves][32];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * h][lm] = acc[r];
+  asum += __shfl_xor(asum, 32);
+  if (h == 0) csum[wave][lm] = asum;
+  __syncthreads();
+  const int lr = tid >> 5, lc = tid & 31, row = m0 + lr, col = n0 + lc;      // one output element per thread
+  if (row < p.M && col < p.N) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < kRowsWaves; ++w) v += part[w][lr][lc];
+    float* dst = p.C + (long)row * p.ldc + col;
+    if (plain) *dst += v;
+    else unsafeAtomicAdd(dst, v);
+  }
+  if (p.a_colsum != nullptr && tile_n == 0 && tid < 32 && m0 + tid < p.M) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < kRowsWaves; ++w) v += csum[w][tid];
+    if (plain) p.a_colsum[m0 + tid] += v;
+    else unsafeAtomicAdd(p.a_colsum + m0 + tid, v);
+  }
+}
+
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace
 
 // Whether the batch should take this kernel: plain products (one tap, no row reduction, no column statistics) whose
 // 64x64 tiling would occupy less than one block per compute unit, with operands the vector loads can address.
+// Row-reduction batches for gemm_skinny_rows_kernel: one tap, no row shifts, a reduction of at most 8192 rows (longer
+// ones fill the chip through the ring kernel's split), at most 128 output tiles (with more, the 32x32 tiles' operand
+// re-reads from L2 cost more than the ring kernel's 64x64 tiles: 20-25 us measured at 384 tiles).
+static bool skinny_rows_applies(const GemmBatch& b) {
+  static const bool off = getenv("OCEAN_GEMM_NO_SKINNY_ROWS") != nullptr;  // measurement switch
+  if (off) return false;
+  long tiles32 = 0;
+  for (int q = 0; q < b.n; ++q) {
+    const GemmP& p = b.g[q];
+    if (!p.a_kmajor || !p.b_kn || p.taps != 1 || (p.T > 0 && p.shift0 != 0)) return false;
+    if (p.K != b.g[0].K || p.K > 8192 || p.K < 64) return false;
+    if ((double)p.K * p.lda >= 5.0e8 || (double)p.K * p.ldb >= 5.0e8) return false;     // 32-bit byte offsets
+    tiles32 += (long)ceil_div(p.M, 32) * ceil_div(p.N, 32);
+  }
+  return tiles32 <= 128;
+}
+
 bool ocean_gemm_skinny_applies(const GemmBatch& b) {
   static const bool off = getenv("OCEAN_GEMM_NO_SKINNY") != nullptr;       // measurement switch
   if (off) return false;
+  if (b.g[0].a_kmajor) return skinny_rows_applies(b);
   long blocks64 = 0, tiles32 = 0;
   for (int q = 0; q < b.n; ++q) {
     const GemmP& p = b.g[q];
@@ -140,7 +242,48 @@ bool ocean_gemm_skinny_applies(const GemmBatch& b) {
   return blocks64 < 256 && tiles32 <= 2048;
 }
 
+static int launch_skinny_rows(const GemmBatch& b, hipStream_t stream) {
+  int tiles = 0;
+  long all_tiles = 0;
+  double flops = 0.0, bytes = 0.0;
+  for (int q = 0; q < b.n; ++q) {
+    const GemmP& p = b.g[q];
+    const int t = ceil_div(p.M, 32) * ceil_div(p.N, 32);
+    if (t > tiles) tiles = t;
+    all_tiles += t;
+    flops += 2.0 * p.M * p.N * (double)p.K;
+    bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+  }
+  // One block per tile unless that leaves most of the chip idle: then the rows are sliced over blocks too, down to
+  // one request round per wave (2 x kRedUnroll rows), the slices adding atomically.
+  const int K = b.g[0].K;
+  int split = 1;
+  if (all_tiles < 64) {
+    split = (int)(128 / (all_tiles > 0 ? all_tiles : 1));
+    const int most = ceil_div(K, kRowsWaves * 2 * kRedUnroll);
+    if (split > most) split = most;
+    if (split < 1) split = 1;
+  }
+  void* tok = nullptr;
+  if (ocean_prof_on()) ocean_prof_begin("gemm_skinny_rows_kernel", flops, bytes, stream, &tok);
+  // plain (non-atomic) accumulation needs every output element to have one writer in this launch: one slice, and no
+  // two problems of the batch whose outputs (or bias-gradient vectors) overlap
+  bool plain = split == 1;
+  for (int q = 0; q < b.n && plain; ++q)
+    for (int r = q + 1; r < b.n && plain; ++r) {
+      const GemmP &x = b.g[q], &y = b.g[r];
+      const float *x0 = x.C, *x1 = x.C + (size_t)(x.M - 1) * x.ldc + x.N, *y0 = y.C, *y1 = y.C + (size_t)(y.M - 1) * y.ldc + y.N;
+      if (x0 < y1 && y0 < x1) plain = false;
+      if (x.a_colsum && y.a_colsum && x.a_colsum < y.a_colsum + y.M && y.a_colsum < x.a_colsum + x.M) plain = false;
+    }
+  hipLaunchKernelGGL(gemm_skinny_rows_kernel, dim3(tiles, b.n, split), dim3(kRowsWaves * 64), 0, stream, b, plain ? 1 : 0);
+  ocean_prof_end(tok, stream);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
 int ocean_launch_gemm_skinny(const GemmBatch& b, hipStream_t stream) {
+  if (b.g[0].a_kmajor) return launch_skinny_rows(b, stream);
   int tiles = 0;
   double flops = 0.0, bytes = 0.0;
   for (int q = 0; q < b.n; ++q) {

@@ -15,7 +15,8 @@ from typing import Optional, Sequence
 import torch
 
 MAX_CONV_LAYERS = 8
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libocean_hip.so")
+# OCEAN_HIP_LIB: another build of the library (A/B measurements); the default is the one built in-tree
+_LIB_PATH = os.environ.get("OCEAN_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libocean_hip.so")
 _lib = None
 
 _STATUS = {1: "bad shape", 2: "unsupported size", 3: "workspace too small", 4: "null pointer",
