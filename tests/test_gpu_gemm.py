@@ -46,7 +46,7 @@ def test_nn_data_gradient(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (64, 64, 1000), (128, 12, 16384), (512, 512, 8192),
-                                   (100, 64, 5000), (129, 257, 777), (512, 512, 131072)])
+                                   (100, 64, 5000), (129, 257, 777), (512, 512, 131072), (200, 130, 9000), (128, 384, 8200)])
 def test_tn_weight_gradient_accumulates(M, N, K):
     from ocean import _hip
     a, b = _rand(K, M, seed=1), _rand(K, N, seed=2)        # reduction over rows

@@ -26,3 +26,28 @@ rows = [(e.key, e.count, e.device_time_total) for e in prof.key_averages() if e.
 rows.sort(key=lambda r: -r[1])
 for k, n, t in rows[:45]:
     print(f"{n:4d}  {t:8.1f} us  {k}")
+
+
+# where the device fills / copies come from: Python call sites of the operators that launch them
+import traceback
+from torch.utils._python_dispatch import TorchDispatchMode
+
+sites = {}
+
+
+class Sites(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if any(k in name for k in ("fill", "zero", "copy", "sort", "cat", "stack", "arange", "ones", "add", "mul", "rand", "full", "empty_like", "clone")):
+            frames = [f for f in traceback.extract_stack() if "/ocean/" in f.filename or f.filename.endswith("bench.py")]
+            key = (name, f"{os.path.relpath(frames[-1].filename, ROOT)}:{frames[-1].lineno}" if frames else "?")
+            sites[key] = sites.get(key, 0) + 1
+        return func(*args, **(kwargs or {}))
+
+
+with Sites():
+    learner.process_tensors(metrics, graph, logs, labels)
+torch.cuda.synchronize()
+print("-- call sites")
+for (name, site), n in sorted(sites.items(), key=lambda kv: -kv[1]):
+    print(f"{n:3d}  {name:32s} {site}")
