@@ -234,7 +234,8 @@ bool ocean_gemm_nt_applies(const GemmBatch& b) {
   const GemmP& p = b.g[0];
   if (p.a_kmajor || p.b_kn || (p.taps != 1 && p.taps != 3)) return false;
   if (p.M % 128 != 0 || p.N % 64 != 0 || p.K % 16 != 0 || p.K < 32) return false;
-  if ((long)(p.M / 128) * (p.N % 128 == 0 ? p.N / 128 : p.N / 64) < 256) return false;
+  static const long min_tiles = [] { const char* e = getenv("OCEAN_GEMM_NT_MIN_TILES"); return e ? atol(e) : 256L; }();   // tuning knob
+  if ((long)(p.M / 128) * (p.N % 128 == 0 ? p.N / 128 : p.N / 64) < min_tiles) return false;
   if (!al16(p.A) || !al16(p.B) || p.lda % 4 != 0 || p.ldb % 4 != 0 || p.tap_stride_b % 4 != 0) return false;
   if ((double)p.M * p.lda >= 5.0e8 || (double)p.N * p.ldb + (double)(p.taps - 1) * (double)p.tap_stride_b >= 5.0e8) return false;
   if (p.taps == 3) {
