@@ -8,9 +8,10 @@
 //    the four values k = 8q + 4h .. + 3 of row m with one ds_read_b128: MFMA t of a group then multiplies k = 8q + t
 //    (lanes h = 0) and k = 8q + 4 + t (h = 1) on both operands alike.  8 fragment reads and 4 staging writes per 16-deep
 //    tile where the k-major layout needs 32 and 10-16;
-//  * a dilated convolution's three taps read ONE staged window of rows: a tile of 128 rows is one sample (T == 128),
-//    its rows sit in LDS between two bands of zero rows (the convolution's padding), and tap t reads the fragments
-//    `shift_t` rows up or down.  The activation tile is loaded and stored once per 16 channels instead of once per tap.
+//  * a dilated convolution's three taps read ONE staged window of rows: a tile of 128 rows is 1, 2 or 4 whole samples
+//    (T = 128, 64, 32), each sample's rows sit in LDS between bands of zero rows (the convolution's padding), and tap t
+//    reads the fragments `shift_t` rows up or down.  The activation tile is loaded and stored once per 16 channels
+//    instead of once per tap.
 // Tiles are always full (the host sends only such problems here), so there is no bounds test anywhere.
 #include "gemm_epilogue.h"
 #include <cstdio>
@@ -24,13 +25,17 @@ constexpr int kPad = 32;                 // zero rows on either side of the wind
 // byte offset of 16-byte quad `kq` of row `r` inside a tile image
 __device__ __forceinline__ unsigned img_off(int r, int kq) { return (unsigned)r * 64u + (unsigned)((kq ^ ((r >> 2) & 3)) << 4); }
 
-template <int BN, int TAPS, bool BNS>
-__global__ __launch_bounds__(kThreads, 3) void gemm_nt_kernel(const GemmBatch batch) {
+// SEG: samples per 128-row tile (three-tap launches; 1 otherwise)
+template <int BN, int TAPS, bool BNS, int SEG = 1>
+__global__ __launch_bounds__(kThreads, SEG == 4 ? 2 : 3) void gemm_nt_kernel(const GemmBatch batch) {
   const GemmP& p = batch.g[blockIdx.y];
   constexpr int BM = 128, BK = 16;
   constexpr int TM = 2, TN = BN / 64;
   constexpr int A_SLOTS = TAPS == 3 ? 2 : 3, B_SLOTS = 3;
-  constexpr int A_ROWS = BM + (TAPS == 3 ? 2 * kPad : 0);
+  constexpr int TS = BM / SEG;                                // rows per sample
+  constexpr int A_ROWS = BM + (TAPS == 3 ? (SEG + 1) * kPad : 0);
+  // window position of tile row r: every sample is preceded by a zero band (and the last one followed by one)
+  auto win_row = [](int r) { return TAPS == 3 ? r + kPad * (1 + r / TS) : r; };
   constexpr int A_SLOT_BYTES = A_ROWS * 64, B_SLOT_BYTES = BN * 64;
   constexpr int A_PIECES = 2, B_PIECES = BN / 64;           // float4 per thread per tile
   __shared__ __align__(16) char smem[A_SLOTS * A_SLOT_BYTES + B_SLOTS * B_SLOT_BYTES];
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_kernel(const GemmBatch ba
   for (int i = 0; i < A_PIECES; ++i) {
     const int idx = tid + i * kThreads, row = idx >> 2, kq = idx & 3;
     a_goff[i] = (unsigned)((m0 + row) * p.lda + kq * 4) * 4u;
-    a_loff[i] = img_off(row + (TAPS == 3 ? kPad : 0), kq);
+    a_loff[i] = img_off(win_row(row), kq);
   }
 #pragma unroll
   for (int i = 0; i < B_PIECES; ++i) {
@@ -93,13 +98,14 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_kernel(const GemmBatch ba
     for (int i = 0; i < B_PIECES; ++i) *reinterpret_cast<float4*>(Bs + slot * B_SLOT_BYTES + b_loff[i]) = rb[i];
   };
 
-  // fragment addresses: this lane's row of sub-tile 0 (sub-tile 1 is 32 rows = 2048 bytes further, same swizzle), one
-  // address per 8-deep half q of a tile and, for the window, per tap
+  // fragment addresses: this lane's row of sub-tile 0 (sub-tile 1 is 32 rows further - 64 when a zero band lies between
+  // them - with the same swizzle), one address per 8-deep half q of a tile and, for the window, per tap
+  constexpr int A_SUB = (TAPS == 3 && SEG == 4) ? 4096 : 2048;
   unsigned a_rd[TAPS][2], b_rd[2];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) {
     const int shift = TAPS == 3 ? p.shift0 + t * p.shift_step : 0;
-    const int r = wm * 64 + lm + (TAPS == 3 ? kPad + shift : 0);
+    const int r = win_row(wm * 64 + lm) + shift;
 #pragma unroll
     for (int q = 0; q < 2; ++q) a_rd[t][q] = img_off(r, 2 * q + h);
   }
@@ -107,11 +113,12 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_kernel(const GemmBatch ba
   for (int q = 0; q < 2; ++q) b_rd[q] = img_off(wn * (BN / 2) + lm, 2 * q + h);
 
   if (TAPS == 3) {
-    // the zero bands of both window slots: rows [0, kPad) and [kPad + BM, A_ROWS), never written again
+    // the zero bands of both window slots (band b: rows [b (TS + kPad), b (TS + kPad) + kPad)), never written again
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int idx = tid; idx < 2 * kPad * 4 * A_SLOTS; idx += kThreads) {
-      const int slot = idx / (2 * kPad * 4), w = idx % (2 * kPad * 4);
-      const int r = (w >> 2) < kPad ? (w >> 2) : (w >> 2) + BM;
+    constexpr int kBandQuads = (SEG + 1) * kPad * 4;
+    for (int idx = tid; idx < kBandQuads * A_SLOTS; idx += kThreads) {
+      const int slot = idx / kBandQuads, w = idx % kBandQuads;
+      const int band = (w >> 2) / kPad, r = band * (TS + kPad) + (w >> 2) % kPad;
       *reinterpret_cast<float4*>(As + slot * A_SLOT_BYTES + r * 64 + (w & 3) * 16) = z;
     }
   }
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_kernel(const GemmBatch ba
   float4 fa[2][TM], fb[2][TN];         // fragments of the two halves of a tile
   auto read_frags = [&](int half, int a_slot, int b_slot, int tap, int q) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[half][i] = *reinterpret_cast<const float4*>(As + a_slot * A_SLOT_BYTES + a_rd[tap][q] + i * 2048);
+    for (int i = 0; i < TM; ++i) fa[half][i] = *reinterpret_cast<const float4*>(As + a_slot * A_SLOT_BYTES + a_rd[tap][q] + i * A_SUB);
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb[half][j] = *reinterpret_cast<const float4*>(Bs + b_slot * B_SLOT_BYTES + b_rd[q] + j * 2048);
   };
@@ -218,16 +225,24 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_nt_kernel(const GemmBatch ba
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-template <int BN, int TAPS>
+template <int BN, int TAPS, int SEG = 1>
 void launch_nt(const GemmBatch& b, dim3 grid, hipStream_t stream) {
-  if (b.g[0].bn_u != nullptr) hipLaunchKernelGGL((gemm_nt_kernel<BN, TAPS, true>), grid, dim3(kThreads), 0, stream, b);
-  else hipLaunchKernelGGL((gemm_nt_kernel<BN, TAPS, false>), grid, dim3(kThreads), 0, stream, b);
+  if (b.g[0].bn_u != nullptr) hipLaunchKernelGGL((gemm_nt_kernel<BN, TAPS, true, SEG>), grid, dim3(kThreads), 0, stream, b);
+  else hipLaunchKernelGGL((gemm_nt_kernel<BN, TAPS, false, SEG>), grid, dim3(kThreads), 0, stream, b);
+}
+template <int BN>
+void launch_nt_taps(const GemmBatch& b, dim3 grid, hipStream_t stream) {
+  const GemmP& p = b.g[0];
+  if (p.taps != 3) launch_nt<BN, 1>(b, grid, stream);
+  else if (p.T == 128) launch_nt<BN, 3, 1>(b, grid, stream);
+  else if (p.T == 64) launch_nt<BN, 3, 2>(b, grid, stream);
+  else launch_nt<BN, 3, 4>(b, grid, stream);
 }
 
 }  // namespace
 
 // One problem, both operands k-contiguous, every tile full, enough tiles to fill the chip; a three-tap problem must have
-// one sample per row tile and symmetric shifts within the zero bands.
+// whole samples in a row tile (T = 128, 64 or 32) and symmetric shifts within the zero bands.
 bool ocean_gemm_nt_applies(const GemmBatch& b) {
   static const bool off = getenv("OCEAN_GEMM_NO_NT") != nullptr;          // measurement switch
   if (off || b.n != 1) return false;
@@ -239,7 +254,7 @@ bool ocean_gemm_nt_applies(const GemmBatch& b) {
   if (!al16(p.A) || !al16(p.B) || p.lda % 4 != 0 || p.ldb % 4 != 0 || p.tap_stride_b % 4 != 0) return false;
   if ((double)p.M * p.lda >= 5.0e8 || (double)p.N * p.ldb + (double)(p.taps - 1) * (double)p.tap_stride_b >= 5.0e8) return false;
   if (p.taps == 3) {
-    if (p.T != 128 || p.shift_step != -p.shift0 || p.shift0 > kPad || p.shift0 < -kPad) return false;
+    if ((p.T != 128 && p.T != 64 && p.T != 32) || p.shift_step != -p.shift0 || p.shift0 > kPad || p.shift0 < -kPad) return false;
   }
   if (p.drop.p > 0.f || p.relu_mask != nullptr || p.a_colsum != nullptr) return false;
   if (p.r_bcast_T > 0 && (p.bn_u == nullptr || p.R == nullptr || p.r_bcast_T % 128 != 0)) return false;
@@ -260,8 +275,8 @@ int ocean_launch_gemm_nt(const GemmBatch& b, hipStream_t stream) {
     if (p.bn_u != nullptr) bytes += 4.0 * (double)p.M * p.N;
     ocean_prof_begin(name, 2.0 * p.M * p.N * (double)p.K * p.taps, bytes, stream, &tok);
   }
-  if (bn == 128) { if (p.taps == 3) launch_nt<128, 3>(b, grid, stream); else launch_nt<128, 1>(b, grid, stream); }
-  else { if (p.taps == 3) launch_nt<64, 3>(b, grid, stream); else launch_nt<64, 1>(b, grid, stream); }
+  if (bn == 128) launch_nt_taps<128>(b, grid, stream);
+  else launch_nt_taps<64>(b, grid, stream);
   ocean_prof_end(tok, stream);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;

@@ -24,6 +24,19 @@ def close(got, ref, tol):
     assert err <= tol * scale, f"max err {err:.3e} scale {scale:.3e}"
 
 
+def close_l2(got, ref, tol, tol_max):
+    """||got - ref||_2 <= tol ||ref||_2 and the largest element error <= tol_max of the largest reference element.
+    For gradients through ReLU over millions of activations: a pre-activation within rounding of zero takes either
+    sign depending on summation order, which moves single rows of a data gradient by their full size and a
+    weight gradient (a sum of ~1e4.5 random-sign terms) by ~1/sqrt(rows) of its size - in the fp32 CPU reference as much
+    as here - so the max-norm at 1e-3 is not a meaningful bound there, the 2-norm is."""
+    got, ref = torch.as_tensor(got).detach().double().cpu(), torch.as_tensor(ref).detach().double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err2, ref2 = (got - ref).norm().item(), max(ref.norm().item(), 1e-12)
+    assert err2 <= tol * ref2, f"l2 err {err2:.3e} ref {ref2:.3e}"
+    assert (got - ref).abs().max().item() <= tol_max * max(ref.abs().max().item(), 1e-3)
+
+
 def build(cin, ch, dil, od, sd, k=3, dropout=0.0):
     from ocean.models.components import DilatedCNN
     m = DilatedCNN(cin, ch, k, dil, dropout=dropout, output_dim=od)
@@ -79,7 +92,8 @@ def test_default_architecture_fixture(golden):
                                             # one sample per 128-row tile and at least 256 tiles: the window kernel serves the
                                             # forward convolutions and, against transposed weights, the data gradients (with the
                                             # BatchNorm sums in the epilogue); dilation 40 is beyond its zero bands
-                                            (256, 128, [64, 128], [3, 32], 3), (256, 128, [64], [40], 3)])
+                                            (256, 128, [64, 128], [3, 32], 3), (256, 128, [64], [40], 3),
+                                            (512, 64, [64, 128], [2, 5], 3), (1024, 32, [64], [7], 3)])
 def test_against_oracle_random(B, T_, ch, dil, k):
     from ocean.models.components import DilatedCNN
     torch.manual_seed(0)
@@ -101,9 +115,14 @@ def test_against_oracle_random(B, T_, ch, dil, k):
     # evaluation-order noise is amplified ~10x there
     gtol = 1e-2 if B * T_ <= 2 else 1e-3
     close(y, yr, 1e-4)
-    close(xg.grad, xr.grad, gtol)
-    for name, p in m.named_parameters():
-        close(p.grad, ref_sd[name].grad, gtol)
+    if B * T_ >= 16384:        # millions of ReLU inputs: see close_l2
+        close_l2(xg.grad, xr.grad, 5e-3, 5e-2)
+        for name, p in m.named_parameters():
+            close_l2(p.grad, ref_sd[name].grad, 5e-3, 5e-2)
+    else:
+        close(xg.grad, xr.grad, gtol)
+        for name, p in m.named_parameters():
+            close(p.grad, ref_sd[name].grad, gtol)
     for name, v in m.state_dict().items():
         if "running" in name:
             close(v, ref_sd[name], 1e-5)

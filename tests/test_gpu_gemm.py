@@ -103,13 +103,15 @@ def test_large_full_tile_products(M, N, K):
 
 # ... and three-tap dilated convolutions whose row tile is one sample (T = 128): the taps read one staged window of
 # rows between zero bands; shifts up to 32 rows, either sign order (forward and data-gradient orientation), and a
-# dilation beyond the bands (falls back to the general kernel).
-@pytest.mark.parametrize("B,Cin,Cout,d,flip", [(256, 64, 128, 1, False), (256, 64, 64, 8, False), (256, 48, 128, 32, True),
-                                               (256, 128, 64, 5, True), (128, 32, 256, 2, False), (256, 64, 128, 40, False),
-                                               (256, 16, 128, 3, False)])
-def test_dilated_conv_window(B, Cin, Cout, d, flip):
+# dilation beyond the bands or a sample length that does not divide the tile (fall back to the general kernel).
+@pytest.mark.parametrize("B,Cin,Cout,d,flip,T", [(256, 64, 128, 1, False, 128), (256, 64, 64, 8, False, 128), (256, 48, 128, 32, True, 128),
+                                                 (256, 128, 64, 5, True, 128), (128, 32, 256, 2, False, 128), (256, 64, 128, 40, False, 128),
+                                                 (256, 16, 128, 3, False, 128),
+                                                 # two and four samples per 128-row tile: a zero band between neighbours
+                                                 (512, 64, 128, 4, False, 64), (512, 48, 64, 31, True, 64), (1024, 32, 128, 2, False, 32),
+                                                 (1024, 64, 64, 32, True, 32), (512, 64, 128, 3, False, 96)])
+def test_dilated_conv_window(B, Cin, Cout, d, flip, T):
     from ocean import _hip
-    T = 128
     M = B * T
     x, w = _rand(M, Cin, seed=1), _rand(3, Cout, Cin, seed=2) * 0.1
     xd, wd = x.cuda(), w.cuda()
@@ -124,7 +126,9 @@ def test_dilated_conv_window(B, Cin, Cout, d, flip):
     for t in range(3):
         s = s0 + t * st
         sh = torch.zeros_like(xs)
-        if s >= 0:
+        if abs(s) >= T:
+            pass
+        elif s >= 0:
             sh[:, :T - s] = xs[:, s:]
         else:
             sh[:, -s:] = xs[:, :T + s]
