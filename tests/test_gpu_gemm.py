@@ -134,3 +134,41 @@ def test_dilated_conv_window(B, Cin, Cout, d, flip, T):
             sh[:, -s:] = xs[:, :T + s]
         ref += sh @ w[t].double().t()
     _close(out, ref.view(M, Cout))
+
+
+def test_window_kernel_random_shapes():
+    """Seeded random shapes across the k-contiguous kernel's domain (tile widths 64 / 128, 1 / 2 / 4 samples per tile,
+    odd and even numbers of 16-deep chunks, shifts up to the band width, both shift orders) against a float64 reference
+    computed on the device."""
+    from ocean import _hip
+    rng = torch.Generator().manual_seed(1234)
+    pick = lambda xs: xs[int(torch.randint(0, len(xs), (1,), generator=rng))]
+    for case in range(16):
+        T = pick([128, 64, 32])
+        Cin, Cout = pick([32, 48, 64, 96, 128, 176]), pick([64, 128, 192, 256])
+        rows_tiles = max(256 // (Cout // (128 if Cout % 128 == 0 else 64)), 1)
+        M = 128 * (rows_tiles + int(torch.randint(0, 9, (1,), generator=rng)))
+        B = M // T
+        d = int(torch.randint(1, 33, (1,), generator=rng))
+        if d >= T:
+            d = T - 1
+        flip = bool(torch.randint(0, 2, (1,), generator=rng))
+        x = torch.randn(M, Cin, generator=rng).cuda()
+        w = (torch.randn(3, Cout, Cin, generator=rng) * 0.1).cuda()
+        out = torch.full((M, Cout), float("nan"), device="cuda")
+        s0, st = (d, -d) if flip else (-d, d)
+        rc = _hip.lib().ocean_conv_gemm_f32(x.data_ptr(), Cin, w.data_ptr(), Cin, out.data_ptr(), Cout, M, Cout, Cin, 0, 0, 3, T, s0, st,
+                                            Cout * Cin, 0, 1, _hip.stream())
+        assert rc == 0
+        xs = x.double().view(B, T, Cin)
+        ref = torch.zeros(B, T, Cout, dtype=torch.float64, device="cuda")
+        for t in range(3):
+            s = s0 + t * st
+            sh = torch.zeros_like(xs)
+            if s >= 0:
+                sh[:, :T - s] = xs[:, s:]
+            else:
+                sh[:, -s:] = xs[:, :T + s]
+            ref += sh @ w[t].double().t()
+        err = (out.double() - ref.view(M, Cout)).abs().max().item()
+        assert err <= 2e-5 * max(ref.abs().max().item(), 1.0), (case, T, Cin, Cout, M, d, flip, err)
