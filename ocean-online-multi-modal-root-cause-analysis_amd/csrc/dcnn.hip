@@ -28,6 +28,7 @@ struct DcnnPlan {
   int M, L, nbn, cmax;
   int width[kMaxBN], in_width[kMaxBN], is_block[kMaxBN], li[kMaxBN];
   size_t h0, u[kMaxBN], a[kMaxBN], pooled;
+  size_t last_cnt, last_sx;      // [B][C] per-sample sums of the last layer's mask and mask * xhat (see bn_apply_pool_kernel)
   size_t stats[kMaxBN], fslots[kMaxBN], mean[kMaxBN], invstd[kMaxBN], scale[kMaxBN], shift[kMaxBN];
   size_t wp[OCEAN_MAX_CONV_LAYERS];
   size_t wpT[OCEAN_MAX_CONV_LAYERS], wtT[OCEAN_MAX_CONV_LAYERS];   // transposed copies: block taps [Kt][Ci][Co], transitions [Ci][Co]
@@ -63,6 +64,8 @@ int make_plan(const ocean_dcnn_shape* s, DcnnPlan* p) {
     p->a[j] = take(M * p->width[j]);
   }
   p->pooled = take((size_t)s->B * s->channels[s->L - 1]);
+  p->last_cnt = take((size_t)s->B * s->channels[s->L - 1]);
+  p->last_sx = take((size_t)s->B * s->channels[s->L - 1]);
   for (int j = 0; j < p->nbn; ++j) {
     const size_t C = p->width[j];
     p->stats[j] = take(4 * C);   // 2*C doubles
@@ -205,6 +208,92 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
       for (int v = 0; v < VEC; ++v) y[v] += q[v];
     }
     store_vec<VEC>(out + i, y);
+  }
+}
+
+// The last layer's apply pass with what follows it folded in.  Its output is only ever averaged over time (the
+// pooling), and in the backward pass its incoming gradient is that pooled gradient broadcast over time: constant per
+// (sample, channel).  So one block takes one sample and 256 channels, walks the sample's T rows once, writes the
+// activation, and leaves per (sample, channel): the time mean (the pooled output - no second pass over the
+// activation), the sum of m_t = [u*scale+shift > 0] * keep_t and the sum of m_t * xhat_t.  The BatchNorm-backward
+// column sums of this layer are then sum_b dpool[b][c]/T * cnt[b][c] and sum_b dpool[b][c]/T * sx[b][c]: a pass over
+// [B, C] instead of one over [B*T, C] (bn_last_reduce_kernel).
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restrict__ u, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ res,
+                                                            float* __restrict__ out, float* __restrict__ pooled,
+                                                            float* __restrict__ cnt, float* __restrict__ sxo, int T, int C, DropoutP dp) {
+  dp = dropout_resolve(dp);
+  __shared__ float red[3][4][256];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c0 = (blockIdx.x * 64 + tx) * 4, b = blockIdx.y;
+  float ps[4] = {0.f, 0.f, 0.f, 0.f}, pc[4] = {0.f, 0.f, 0.f, 0.f}, px[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c0 < C) {
+    float sc[4], sh[4], mu[4], is[4];
+    load_vec<4>(scale + c0, sc); load_vec<4>(shift + c0, sh); load_vec<4>(mean + c0, mu); load_vec<4>(invstd + c0, is);
+#pragma unroll 2
+    for (int t = ty; t < T; t += 4) {
+      const long i = ((long)b * T + t) * C + c0;
+      float x[4], y[4];
+      load_vec<4>(u + i, x);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float z = fmaf(x[v], sc[v], sh[v]);
+        float m = z > 0.f ? 1.f : 0.f;
+        if (dp.p > 0.f) m *= dropout_keep(dp, (uint64_t)(i + v));
+        y[v] = fmaxf(z, 0.f) * (dp.p > 0.f ? m : 1.f);
+        pc[v] += m;
+        px[v] = fmaf(m, (x[v] - mu[v]) * is[v], px[v]);
+      }
+      if (res) {
+        float q[4];
+        load_vec<4>(res + i, q);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) y[v] += q[v];
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) ps[v] += y[v];
+      store_vec<4>(out + i, y);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) { red[0][ty][tx * 4 + v] = ps[v]; red[1][ty][tx * 4 + v] = pc[v]; red[2][ty][tx * 4 + v] = px[v]; }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    const int l = threadIdx.x;
+    const long o = (long)b * C + c;
+    pooled[o] = (red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l]) * (1.0f / (float)T);
+    cnt[o] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    sxo[o] = red[2][0][l] + red[2][1][l] + red[2][2][l] + red[2][3][l];
+  }
+}
+
+// bslots += (sum_b dpool*cnt, sum_b dpool*sx) / T for the last layer: a block takes 64 channels of kLastRows samples
+// and adds its partial sums into slot copy blockIdx.y % kStatSlots
+constexpr int kLastRows = 32;
+__global__ __launch_bounds__(256) void bn_last_reduce_kernel(const float* __restrict__ dpool, const float* __restrict__ cnt,
+                                                             const float* __restrict__ sxi, double* __restrict__ bslots, int B, int C, float inv_T) {
+  __shared__ float red[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int b0 = blockIdx.y * kLastRows, b1 = min(B, b0 + kLastRows);
+  float sg = 0.f, sx = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (int b = b0 + ty; b < b1; b += 4) {
+      const long o = (long)b * C + c;
+      const float g = dpool[o] * inv_T;
+      sg = fmaf(g, cnt[o], sg);
+      sx = fmaf(g, sxi[o], sx);
+    }
+  }
+  red[0][ty][tx] = sg; red[1][ty][tx] = sx;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    double* slot = bslots + (size_t)(blockIdx.y % kStatSlots) * 2 * C;
+    unsafeAtomicAdd(slot + c, (double)(red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx]));
+    unsafeAtomicAdd(slot + C + c, (double)(red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx]));
   }
 }
 
@@ -431,6 +520,12 @@ int conv_fwd(const DcnnPlan& pl, const ocean_dcnn_shape* s, int j, const float* 
   return OCEAN_OK;
 }
 
+// whether the last layer's apply pass also pools and leaves the per-sample sums its backward reduction needs
+inline bool last_pool_fused(const DcnnPlan& pl) {
+  static const bool off = getenv("OCEAN_DCNN_SEPARATE_POOL") != nullptr;     // measurement switch
+  return !off && pl.width[pl.nbn - 1] % 4 == 0;
+}
+
 const float* layer_input(const DcnnPlan& pl, int j, const float* ws) { return j == 0 ? ws + pl.h0 : ws + pl.a[j - 1]; }
 
 }  // namespace
@@ -501,12 +596,21 @@ int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* para
       const int j = ph - 1;   // finish BN layer j
       // the statistics were collapsed (and possibly all-reduced by the caller) iff this call starts at this phase
       OCEAN_TRY(bn_finalize(pl, s, j, params, ws, s->training && ph > phase_lo, st));
-      OCEAN_TRY(bn_apply_fwd(pl, s, j, ws, pl.is_block[j] ? layer_input(pl, j, ws) : nullptr, st));
+      const bool pool_fused = ph == nph - 1 && last_pool_fused(pl);
+      if (pool_fused) {
+        const int C = pl.width[j];
+        hipLaunchKernelGGL(bn_apply_pool_kernel, dim3(ceil_div(C, 256), s->B), dim3(256), 0, st, ws + pl.u[j], ws + pl.scale[j],
+                           ws + pl.shift[j], ws + pl.mean[j], ws + pl.invstd[j], pl.is_block[j] ? layer_input(pl, j, ws) : nullptr,
+                           ws + pl.a[j], ws + pl.pooled, ws + pl.last_cnt, ws + pl.last_sx, s->T, C, layer_dropout(s, j));
+        OCEAN_LAUNCH_CHECK();
+      } else {
+        OCEAN_TRY(bn_apply_fwd(pl, s, j, ws, pl.is_block[j] ? layer_input(pl, j, ws) : nullptr, st));
+      }
       if (ph < nph - 1) {
         OCEAN_TRY(conv_fwd(pl, s, j + 1, ws + pl.a[j], params, ws, ph + 1 >= phase_hi, st));
       } else {
         const int C = s->channels[L - 1];
-        OCEAN_TRY(mean_mid(ws + pl.a[j], ws + pl.pooled, s->B, s->T, C, st));
+        if (!pool_fused) OCEAN_TRY(mean_mid(ws + pl.a[j], ws + pl.pooled, s->B, s->T, C, st));
         OCEAN_TRY(linear_fwd(ws + pl.pooled, C, params[pi_out(L, 0)], params[pi_out(L, 1)], out, s->out_dim, s->B, s->out_dim, C, 0, st));
       }
     }
@@ -543,6 +647,13 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
     const int bT = last ? s->T : 0;
     const float sc = last ? 1.0f / (float)s->T : 1.0f;
     double* slots = reinterpret_cast<double*>(wb + pl.bslots[j]);
+    if (last && last_pool_fused(pl)) {
+      // the forward pass left this layer's per-sample mask sums: the reduction runs over [B, C]
+      hipLaunchKernelGGL(bn_last_reduce_kernel, dim3(ceil_div(C, 64), ceil_div(s->B, kLastRows)), dim3(256), 0, st, wb + pl.dpool, wf + pl.last_cnt, wf + pl.last_sx,
+                         slots, s->B, C, sc);
+      OCEAN_LAUNCH_CHECK();
+      return OCEAN_OK;
+    }
     // about 1024 row blocks: every block ends with 2*C fp64 atomics, and measured over 256..8192 blocks the pass is
     // fastest here (fewer blocks leave CUs idle at the tail, more pile up on the atomics)
     const int min_rows = ceil_div(M, 1024);
