@@ -108,8 +108,15 @@ int ocean_dcnn_stats_block(const ocean_dcnn_shape* s, int phase, int backward,
 
 /* Offset (in floats, into the forward workspace) and width C of dilated block `block`'s output activation
  * [B*T, C] (after BatchNorm, ReLU, dropout and the residual), valid after ocean_dcnn_fwd.  It is what
- * DilatedCNN.get_temporal_features pools per layer (dilated_cnn.py:243-277). */
+ * DilatedCNN.get_temporal_features pools per layer (dilated_cnn.py:243-277).  The LAST block's activation is not kept
+ * when its width is a multiple of 4 (the pass that would write it pools it over time instead): status 2, use
+ * ocean_dcnn_pooled_output. */
 int ocean_dcnn_block_output(const ocean_dcnn_shape* s, int block, size_t* offset_floats, int* width);
+
+/* Offset (in floats, into the forward workspace) and width of the last block's output averaged over time, [B, C]:
+ * the input of DilatedCNN's output projection (dilated_cnn.py:221-223, global_pooling == 'mean'), valid after
+ * ocean_dcnn_fwd. */
+int ocean_dcnn_pooled_output(const ocean_dcnn_shape* s, size_t* offset_floats, int* width);
 
 int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* params,
                    float* ws, size_t ws_floats, float* out /* [B,out_dim] */,

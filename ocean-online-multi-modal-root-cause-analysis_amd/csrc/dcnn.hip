@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float* __restri
 
 // The last layer's apply pass with what follows it folded in.  Its output is only ever averaged over time (the
 // pooling), and in the backward pass its incoming gradient is that pooled gradient broadcast over time: constant per
-// (sample, channel).  So one block takes one sample and 256 channels, walks the sample's T rows once, writes the
-// activation, and leaves per (sample, channel): the time mean (the pooled output - no second pass over the
+// (sample, channel).  So one block takes one sample and 256 channels, walks the sample's T rows once and leaves per
+// (sample, channel) - the activation itself is not written unless `out` is given -: the time mean (the pooled output - no second pass over the
 // activation), the sum of m_t = [u*scale+shift > 0] * keep_t and the sum of m_t * xhat_t.  The BatchNorm-backward
 // column sums of this layer are then sum_b dpool[b][c]/T * cnt[b][c] and sum_b dpool[b][c]/T * sx[b][c]: a pass over
 // [B, C] instead of one over [B*T, C] (bn_last_reduce_kernel).
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float* __restr
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) ps[v] += y[v];
-      store_vec<4>(out + i, y);
+      if (out != nullptr) store_vec<4>(out + i, y);
     }
   }
 #pragma unroll
@@ -559,8 +559,17 @@ int ocean_dcnn_block_output(const ocean_dcnn_shape* s, int block, size_t* offset
   DcnnPlan p;
   OCEAN_TRY(make_plan(s, &p));
   if (block < 0 || block >= s->L) return OCEAN_ERR_BAD_SHAPE;
+  if (block == s->L - 1 && last_pool_fused(p)) return OCEAN_ERR_UNSUPPORTED;   // only its time mean is kept: ocean_dcnn_pooled_output
   if (offset_floats) *offset_floats = p.a[2 * block];      // BN layers alternate block, transition, block, ...
   if (width) *width = p.width[2 * block];
+  return OCEAN_OK;
+}
+
+int ocean_dcnn_pooled_output(const ocean_dcnn_shape* s, size_t* offset_floats, int* width) {
+  DcnnPlan p;
+  OCEAN_TRY(make_plan(s, &p));
+  if (offset_floats) *offset_floats = p.pooled;
+  if (width) *width = s->channels[s->L - 1];
   return OCEAN_OK;
 }
 
@@ -601,7 +610,7 @@ int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* para
         const int C = pl.width[j];
         hipLaunchKernelGGL(bn_apply_pool_kernel, dim3(ceil_div(C, 256), s->B), dim3(256), 0, st, ws + pl.u[j], ws + pl.scale[j],
                            ws + pl.shift[j], ws + pl.mean[j], ws + pl.invstd[j], pl.is_block[j] ? layer_input(pl, j, ws) : nullptr,
-                           ws + pl.a[j], ws + pl.pooled, ws + pl.last_cnt, ws + pl.last_sx, s->T, C, layer_dropout(s, j));
+                           nullptr, ws + pl.pooled, ws + pl.last_cnt, ws + pl.last_sx, s->T, C, layer_dropout(s, j));
         OCEAN_LAUNCH_CHECK();
       } else {
         OCEAN_TRY(bn_apply_fwd(pl, s, j, ws, pl.is_block[j] ? layer_input(pl, j, ws) : nullptr, st));

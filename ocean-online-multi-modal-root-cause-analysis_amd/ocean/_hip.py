@@ -147,6 +147,7 @@ def _declare_rest(lib) -> None:
     sig("ocean_bce_elem_fwd", c_int, vp, vp, c_long, vp, vp)
     sig("ocean_bce_elem_bwd", c_int, vp, vp, vp, c_long, vp, vp)
     sig("ocean_dcnn_block_output", c_int, POINTER(DcnnShape), c_int, POINTER(c_size_t), POINTER(c_int))
+    sig("ocean_dcnn_pooled_output", c_int, POINTER(DcnnShape), POINTER(c_size_t), POINTER(c_int))
     sig("ocean_gnn_layer_output", c_int, POINTER(GnnShape), c_int, POINTER(c_size_t), POINTER(c_int))
     sig("ocean_gnn_edge_kernel_family", c_int, POINTER(GnnShape))
     sig("ocean_prof_enable", c_int, c_int)

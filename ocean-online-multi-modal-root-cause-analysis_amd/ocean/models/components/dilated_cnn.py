@@ -246,8 +246,14 @@ class DilatedCNN(nn.Module):
             feats = []
             for i in range(shape.L):
                 off, width = ctypes.c_size_t(0), ctypes.c_int(0)
-                _hip.check(L.ocean_dcnn_block_output(ctypes.byref(shape), i, ctypes.byref(off), ctypes.byref(width)),
-                           "ocean_dcnn_block_output")
+                rc = L.ocean_dcnn_block_output(ctypes.byref(shape), i, ctypes.byref(off), ctypes.byref(width))
+                if rc == 2 and i == shape.L - 1:
+                    # the last block's activation is pooled by the pass that would have written it: take the means
+                    _hip.check(L.ocean_dcnn_pooled_output(ctypes.byref(shape), ctypes.byref(off), ctypes.byref(width)),
+                               "ocean_dcnn_pooled_output")
+                    feats.append(ws[off.value: off.value + shape.B * width.value].view(shape.B, width.value).clone())
+                    continue
+                _hip.check(rc, "ocean_dcnn_block_output")
                 act = ws[off.value: off.value + shape.B * shape.T * width.value].view(shape.B, shape.T, width.value)
                 pooled = torch.empty(shape.B, width.value, device=x.device, dtype=torch.float32)
                 _hip.check(L.ocean_mean_mid_f32(_hip.dev_ptr(act), _hip.dev_ptr(pooled), shape.B, shape.T, width.value,
