@@ -208,7 +208,7 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 // Whether the batch should take this kernel: plain products (one tap, no row reduction, no column statistics) whose
 // 64x64 tiling would occupy less than one block per compute unit, with operands the vector loads can address.
 // Row-reduction batches for gemm_skinny_rows_kernel: one tap, no row shifts, a reduction of at most 8192 rows (longer
-// ones fill the chip through the ring kernel's split), at most 128 output tiles (with more, the 32x32 tiles' operand
+// ones fill the chip through the ring kernel's split, unless the output is a handful of tiles), at most 128 output tiles (with more, the 32x32 tiles' operand
 // re-reads from L2 cost more than the ring kernel's 64x64 tiles: 20-25 us measured at 384 tiles).
 static bool skinny_rows_applies(const GemmBatch& b) {
   static const bool off = getenv("OCEAN_GEMM_NO_SKINNY_ROWS") != nullptr;  // measurement switch
@@ -217,10 +217,15 @@ static bool skinny_rows_applies(const GemmBatch& b) {
   for (int q = 0; q < b.n; ++q) {
     const GemmP& p = b.g[q];
     if (!p.a_kmajor || !p.b_kn || p.taps != 1 || (p.T > 0 && p.shift0 != 0)) return false;
-    if (p.K != b.g[0].K || p.K > 8192 || p.K < 64) return false;
+    if (p.K != b.g[0].K || p.K < 64) return false;
     if ((double)p.K * p.lda >= 5.0e8 || (double)p.K * p.ldb >= 5.0e8) return false;     // 32-bit byte offsets
     tiles32 += (long)ceil_div(p.M, 32) * ceil_div(p.N, 32);
   }
+  // long reductions only into one or two tiles (the temporal encoder's input projection: a 64 x 12 weight gradient over
+  // 131 072 rows, 42 us through the ring kernel's 64x64 tiles, 19 us here as 256 row slices; at 8 and 16 tiles the
+  // slices' atomic adds make this kernel the slower one: 44 and 129 us)
+  static const int long_tiles = [] { const char* e = getenv("OCEAN_GEMM_ROWS_LONG_TILES"); return e ? atoi(e) : 2; }();
+  if (b.g[0].K > 8192) return tiles32 <= long_tiles;
   return tiles32 <= 128;
 }
 
@@ -260,6 +265,11 @@ static int launch_skinny_rows(const GemmBatch& b, hipStream_t stream) {
   int split = 1;
   if (all_tiles < 64) {
     split = (int)(128 / (all_tiles > 0 ? all_tiles : 1));
+    // a long reduction: two request rounds per wave, as long as the slices' atomic adds stay below ~half a million
+    if (K > 8192) {
+      const long by_rows = ceil_div(K, kRowsWaves * 4 * kRedUnroll), by_adds = 512 / (all_tiles > 0 ? all_tiles : 1);
+      split = (int)(by_rows < by_adds ? by_rows : by_adds);
+    }
     const int most = ceil_div(K, kRowsWaves * 2 * kRedUnroll);
     if (split > most) split = most;
     if (split < 1) split = 1;
