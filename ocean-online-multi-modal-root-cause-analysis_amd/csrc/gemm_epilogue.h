@@ -63,10 +63,10 @@ __device__ __forceinline__ void epilogue_full(f32x16 (&acc)[TM][TN], const EpiAr
   const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(u_w), 0, 0x7FFFFFF0, 0x00020000);
   if constexpr (bn_on) {
     // With the BatchNorm sums riding along every output element needs its saved u (and its residual) from memory.
-    // The elements go in groups of eight, and the loads of group g+1 are issued before group g is worked on, so
+    // The elements go in groups of sixteen (one 32x32 sub-tile), and the loads of group g+1 are issued before group g is worked on, so
     // the block waits for memory once, not once per group; the per-column constants of all column groups are
     // fetched up front for the same reason.  (By now the main loop's staging and fragment registers are free.)
-    constexpr int G = 8, GPS = 16 / G, NG = TN * TM * GPS;
+    constexpr int G = 16, GPS = 16 / G, NG = TN * TM * GPS;
     const bool bcast_r = has_r && e.r_bcast_T > 0;
     float sc_[TN], sh_[TN], mu_[TN], is_[TN], rb_[TN];
 #pragma unroll
