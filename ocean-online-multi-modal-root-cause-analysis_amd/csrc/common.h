@@ -148,6 +148,10 @@ int ocean_launch_gemm_skinny(const GemmBatch& b, hipStream_t stream);
 bool ocean_gemm_nt_applies(const GemmBatch& b);
 int ocean_launch_gemm_nt(const GemmBatch& b, hipStream_t stream);
 
+// the kernel for long row reductions into full 128x128 tiles (gemm_tn.hip), likewise
+bool ocean_gemm_tn_applies(const GemmBatch& b);
+int ocean_launch_gemm_tn(const GemmBatch& b, hipStream_t stream);
+
 // optional kernel timing (prof.hip); token is null while profiling is off
 bool ocean_prof_on();
 void ocean_prof_begin(const char* name, double flops, double bytes, hipStream_t s, void** token);

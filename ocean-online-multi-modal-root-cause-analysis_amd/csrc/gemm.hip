@@ -634,6 +634,7 @@ int ocean_launch_gemm_batch(const GemmP* ps, int n, hipStream_t stream) {
   for (int q = n; q < kGemmBatchMax; ++q) b.g[q] = ps[0];
   if (ocean_gemm_skinny_applies(b)) return ocean_launch_gemm_skinny(b, stream);
   if (aligned && ocean_gemm_nt_applies(b)) return ocean_launch_gemm_nt(b, stream);
+  if (aligned && ocean_gemm_tn_applies(b)) return ocean_launch_gemm_tn(b, stream);
   if (ps[0].a_kmajor) return launch_mode<true, true>(b, aligned, stream);
   if (ps[0].b_kn) return launch_mode<false, true>(b, aligned, stream);
   return launch_mode<false, false>(b, aligned, stream);
