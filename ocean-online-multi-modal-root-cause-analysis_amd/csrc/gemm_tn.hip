@@ -7,7 +7,7 @@
 // host sends only problems whose tiles are full, whose slices are whole 16-row tiles and whose samples are multiples of
 // 16 rows long, so a staged piece needs no bounds arithmetic beyond one compare for the time window of a shifted row;
 // tile coordinates are two scalar adds; fragments are read half a tile (16 MFMAs) ahead.  Per 16-deep tile the general
-// kernel's loop carries ~48 vector, ~49 scalar and ~34 wait instructions next to its 32 MFMAs, this one ~10, ~8 and ~6.
+// kernel's loop carries ~48 vector, ~49 scalar and ~34 wait instructions next to its 32 MFMAs, this one ~19, ~9 and ~6.
 #include "gemm_epilogue.h"
 #include <cmath>
 #include <cstdio>
