@@ -172,3 +172,28 @@ def test_window_kernel_random_shapes():
             ref += sh @ w[t].double().t()
         err = (out.double() - ref.view(M, Cout)).abs().max().item()
         assert err <= 2e-5 * max(ref.abs().max().item(), 1.0), (case, T, Cin, Cout, M, d, flip, err)
+
+
+def test_large_kernels_with_padded_leading_dimensions():
+    """The k-contiguous product and the long row reduction on operands that are column blocks of wider matrices
+    (leading dimensions larger than the logical widths), writing into a column block of a wider output."""
+    from ocean import _hip
+    L = _hip.lib()
+    # NT: A [M, K] inside [M, K + 16], W [N, K] inside [N, K + 32], C [M, N] inside [M, N + 64]
+    M, N, K = 32768, 128, 96
+    abig, wbig = _rand(M, K + 16, seed=1).cuda(), _rand(N, K + 32, seed=2).cuda()
+    cbig = torch.zeros(M, N + 64, device="cuda")
+    a, w, c = abig[:, 16:], wbig[:, 32:], cbig[:, 64:]
+    assert L.ocean_gemm_f32(a.data_ptr(), K + 16, w.data_ptr(), K + 32, c.data_ptr(), N + 64, M, N, K, 0, 0, None, None, 0, 0, _hip.stream()) == 0
+    torch.cuda.synchronize()
+    _close(c, (a.double() @ w.double().t()).cpu())
+    assert float(cbig[:, :64].abs().sum()) == 0
+    # TN: dY [K, M] inside [K, M + 8], X [K, N] inside [K, N + 12], accumulated into dW [M, N] inside [M, N + 4]
+    M, N, K = 128, 256, 16384
+    ybig, xbig = _rand(K, M + 8, seed=3).cuda(), _rand(K, N + 12, seed=4).cuda()
+    dbig = torch.ones(M, N + 4, device="cuda")
+    y, x, d = ybig[:, 8:], xbig[:, 12:], dbig[:, 4:]
+    assert L.ocean_gemm_f32(y.data_ptr(), M + 8, x.data_ptr(), N + 12, d.data_ptr(), N + 4, M, N, K, 1, 1, None, None, 0, 0, _hip.stream()) == 0
+    torch.cuda.synchronize()
+    _close(d, (1.0 + y.double().t() @ x.double()).cpu(), 5e-5)
+    assert bool((dbig[:, :4] == 1).all())
