@@ -126,6 +126,16 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
                    const float* dout /* [B,out_dim] */, float* const* grads,
                    float* dx /* [B,T,F] or NULL */, int phase_lo, int phase_hi, void* stream);
 
+/* One backward phase in two calls, for data-parallel callers that all-reduce the statistics block between phases:
+ * part 0 launches what the next phase's statistics wait for (the layer's BatchNorm-backward apply pass, its data
+ * gradient, the column sums of the layer below), part 1 the rest (the layer's weight gradient; in the last phase the
+ * input projection's gradients and the unpacking of the per-tap weight gradients).  Start the all-reduce after part 0,
+ * run part 1 under it, wait before the next phase's part 0.  Phase 0 is all part 0.  No counterpart in the reference
+ * (which has no distributed code); ocean_dcnn_bwd(phase, phase + 1) == part 0 then part 1. */
+int ocean_dcnn_bwd_part(const ocean_dcnn_shape* s, const float* x, float* const* params,
+                        float* ws_fwd, float* ws_bwd, size_t ws_bwd_floats,
+                        const float* dout, float* const* grads, float* dx, int phase, int part, void* stream);
+
 /* ------------------------------------------------------------------ GraphNeuralNetwork (GAT)
  * Replaces GraphNeuralNetwork.forward with conv_type='gat', pooling='mean',
  * batch_norm=False (ocean/models/components/graph_neural_network.py:236-302),

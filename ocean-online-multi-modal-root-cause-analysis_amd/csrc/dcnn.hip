@@ -627,8 +627,16 @@ int ocean_dcnn_fwd(const ocean_dcnn_shape* s, const float* x, float* const* para
   return OCEAN_OK;
 }
 
-int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* params, float* wf, float* wb, size_t wb_floats,
-                   const float* dout, float* const* grads, float* dx, int phase_lo, int phase_hi, void* stream) {
+}  // extern "C"
+
+namespace {
+
+// parts: 1 = what the NEXT phase's statistics wait for (this layer's BatchNorm-backward apply pass and data gradient, the
+// column sums of the layer below), 2 = the rest of the phase (the layer's weight gradient; in the last phase also the
+// input projection's gradients and the unpacking of the per-tap weight gradients).  A data-parallel caller runs part 1,
+// starts the all-reduce of the statistics block, runs part 2 under it, and waits before the next phase.
+int dcnn_bwd_impl(const ocean_dcnn_shape* s, const float* x, float* const* params, float* wf, float* wb, size_t wb_floats,
+                  const float* dout, float* const* grads, float* dx, int phase_lo, int phase_hi, int parts, void* stream) {
   DcnnPlan pl;
   OCEAN_TRY(make_plan(s, &pl));
   if (!x || !params || !wf || !wb || !dout || !grads) return OCEAN_ERR_NULL;
@@ -704,8 +712,10 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
 
   auto nt_form = [](const GemmP& g) { GemmBatch b; b.n = 1; b.g[0] = g; return ocean_gemm_nt_applies(b); };
 
+  const bool part_a = (parts & 1) != 0, part_b = (parts & 2) != 0;
   for (int ph = phase_lo; ph < phase_hi; ++ph) {
     if (ph == 0) {
+      if (!part_a) continue;
       OCEAN_TRY(zero_f32(wb + pl.bstats[0], pl.bwd_total - pl.bstats[0], st));   // bstats + packed weight grads
       // output projection
       OCEAN_TRY(linear_bwd_weight(dout, s->out_dim, wf + pl.pooled, Cl, grads[pi_out(L, 0)], s->B, s->out_dim, Cl, st, grads[pi_out(L, 1)]));   // + bias gradient (column sums of the same operand)
@@ -722,7 +732,8 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
     const float dsc = last ? 1.0f / (float)s->T : 1.0f;
     const double* bs = reinterpret_cast<const double*>(wb + pl.bstats[j]);
     float* dU = wb + pl.dU;
-    if (C % 4 == 0) {
+    if (!part_a) {}
+    else if (C % 4 == 0) {
       const ColTile ct = col_tile(C, 4, M, 8, 1);
       hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, col_grid(ct, C, 4, M), dim3(256), 0, st, dy, bT, dsc, wf + pl.u[j], wf + pl.scale[j],
                          wf + pl.shift[j], wf + pl.mean[j], wf + pl.invstd[j], bs, n, dU, M, C, s->training, ct, layer_dropout(s, j));
@@ -736,13 +747,6 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
     bool rode = false;
     if (pl.is_block[j]) {
       const int i = pl.li[j], k = s->kernel_size, d = s->dilations[i];
-      // weight gradient per tap into the packed buffer
-      GemmP g = gemm_defaults();
-      g.A = dU; g.lda = C; g.a_kmajor = 1; g.B = in; g.ldb = Cin; g.b_kn = 1;
-      g.C = wb + pl.dwp[i]; g.ldc = Cin; g.M = C; g.N = Cin; g.K = M; g.split_k = 0;
-      g.taps = k; g.tap_stride_c = (long)C * Cin;
-      if (k > 1) { g.T = s->T; g.shift0 = -(k / 2) * d; g.shift_step = d; }
-      OCEAN_TRY(ocean_launch_gemm(g, st));       // (the packed gradients of all blocks are unpacked together at the end)
       // data gradient: taps with the opposite shift, plus the identity-residual gradient.  Preferred form: both operands
       // with the reduction index (the output channels) contiguous, i.e. against the transposed weight copy; the
       // [k][n] form serves the shapes that kernel does not take.
@@ -761,10 +765,19 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
         h.B = wf + pl.wp[i]; h.ldb = Cin; h.b_kn = 1;
         if (j > 0) rode = ride_along(h, j - 1);
       }
-      OCEAN_TRY(ocean_launch_gemm(h, st));
+      if (part_a) OCEAN_TRY(ocean_launch_gemm(h, st));
+      if (part_b) {
+        // weight gradient per tap into the packed buffer (the packed gradients of all blocks are unpacked together at the end)
+        GemmP g = gemm_defaults();
+        g.A = dU; g.lda = C; g.a_kmajor = 1; g.B = in; g.ldb = Cin; g.b_kn = 1;
+        g.C = wb + pl.dwp[i]; g.ldc = Cin; g.M = C; g.N = Cin; g.K = M; g.split_k = 0;
+        g.taps = k; g.tap_stride_c = (long)C * Cin;
+        if (k > 1) { g.T = s->T; g.shift0 = -(k / 2) * d; g.shift_step = d; }
+        OCEAN_TRY(ocean_launch_gemm(g, st));
+      }
     } else {
       const int i = pl.li[j];
-      OCEAN_TRY(linear_bwd_weight(dU, C, in, Cin, grads[pi_trans(L, i, 0)], M, C, Cin, st));
+      if (part_b) OCEAN_TRY(linear_bwd_weight(dU, C, in, Cin, grads[pi_trans(L, i, 0)], M, C, Cin, st));
       GemmP h = gemm_defaults();        // dx = dU . W: against the transposed copy [Cin][C] when that kernel takes the shape, else W [C, Cin] read as [k][n]
       h.A = dU; h.lda = C; h.C = grad_buf(j - 1); h.ldc = Cin;
       h.M = M; h.N = Cin; h.K = C;
@@ -776,12 +789,14 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
         h.B = params[pi_trans(L, i, 0)]; h.ldb = Cin; h.b_kn = 1;
         rode = ride_along(h, j - 1);
       }
-      OCEAN_TRY(ocean_launch_gemm(h, st));
+      if (part_a) OCEAN_TRY(ocean_launch_gemm(h, st));
     }
     if (j > 0) {
-      if (!rode) OCEAN_TRY(reduce(j - 1));
-      OCEAN_TRY(reduce_finish(j - 1));
-    } else {
+      if (part_a) {
+        if (!rode) OCEAN_TRY(reduce(j - 1));
+        OCEAN_TRY(reduce_finish(j - 1));
+      }
+    } else if (part_b) {
       // input projection: grad wrt h0 sits in grad_buf(0)
       const float* dh0 = grad_buf(0);
       const int C0 = s->channels[0];
@@ -800,6 +815,21 @@ int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* para
     }
   }
   return OCEAN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* params, float* wf, float* wb, size_t wb_floats,
+                   const float* dout, float* const* grads, float* dx, int phase_lo, int phase_hi, void* stream) {
+  return dcnn_bwd_impl(s, x, params, wf, wb, wb_floats, dout, grads, dx, phase_lo, phase_hi, 3, stream);
+}
+
+int ocean_dcnn_bwd_part(const ocean_dcnn_shape* s, const float* x, float* const* params, float* wf, float* wb, size_t wb_floats,
+                        const float* dout, float* const* grads, float* dx, int phase, int part, void* stream) {
+  if (part != 0 && part != 1) return OCEAN_ERR_BAD_SHAPE;
+  return dcnn_bwd_impl(s, x, params, wf, wb, wb_floats, dout, grads, dx, phase, phase + 1, part == 0 ? 1 : 2, stream);
 }
 
 }  // extern "C"

@@ -63,6 +63,8 @@ def _declare(lib) -> None:
     lib.ocean_dcnn_bwd.restype = c_int
     lib.ocean_dcnn_bwd.argtypes = [sp, c_void_p, POINTER(c_void_p), c_void_p, c_void_p, c_size_t, c_void_p,
                                    POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p]
+    lib.ocean_dcnn_bwd_part.restype = c_int
+    lib.ocean_dcnn_bwd_part.argtypes = lib.ocean_dcnn_bwd.argtypes
 
 
 class MfaShape(ctypes.Structure):

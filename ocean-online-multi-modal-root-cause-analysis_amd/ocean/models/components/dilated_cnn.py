@@ -93,13 +93,27 @@ class _DcnnFunction(torch.autograd.Function):
             _hip.check(L.ocean_dcnn_bwd(ctypes.byref(shape), _hip.dev_ptr(x), ptab, _hip.dev_ptr(ws), _hip.dev_ptr(wb),
                                         wb.numel(), _hip.dev_ptr(dout, "grad_output"), gtab, _hip.dev_ptr(dx),
                                         lo, hi, _hip.stream()), "ocean_dcnn_bwd")
+        start = module.stats_all_reduce_start if shape.training else None
         if sync is None:
             run(0, nph)
-        else:
+        elif start is None:
             for ph in range(nph):
                 run(ph, ph + 1)
                 if ph < nph - 1:
                     sync(module._stats_view(shape, wb, ph, True))
+        else:
+            # the statistics block of the layer below is complete after the first part of a phase: its all-reduce
+            # travels while the second part (this layer's weight gradient) runs, and is waited for before the next phase
+            def part(ph, which):
+                _hip.check(L.ocean_dcnn_bwd_part(ctypes.byref(shape), _hip.dev_ptr(x), ptab, _hip.dev_ptr(ws), _hip.dev_ptr(wb),
+                                                 wb.numel(), _hip.dev_ptr(dout, "grad_output"), gtab, _hip.dev_ptr(dx),
+                                                 ph, which, _hip.stream()), "ocean_dcnn_bwd_part")
+            for ph in range(nph):
+                part(ph, 0)
+                work = start(module._stats_view(shape, wb, ph, True)) if ph < nph - 1 else None
+                part(ph, 1)
+                if work is not None:
+                    work.wait()
         out = [dx, None]
         for i, g in enumerate(grads):
             out.append(g if (g is not None and ctx.needs_input_grad[2 + i]) else None)
@@ -141,6 +155,9 @@ class DilatedCNN(nn.Module):
         # data-parallel hook: callable(all-reduce) applied to each fp64 BatchNorm
         # statistics block, and the global number of rows behind those statistics
         self.stats_all_reduce: Optional[Callable[[torch.Tensor], None]] = None
+        # optional asynchronous form for the backward pass: returns a handle whose wait() orders the current stream
+        # behind the reduction (the weight gradient of the layer above runs in between)
+        self.stats_all_reduce_start: Optional[Callable[[torch.Tensor], object]] = None
         self.stats_world_size: int = 1
         # optional callable(local batch) -> samples of this step summed over the ranks, for ranks whose batches differ in
         # size (default: stats_world_size * local batch)

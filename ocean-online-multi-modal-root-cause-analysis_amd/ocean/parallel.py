@@ -222,6 +222,7 @@ class DataParallel:
         enc = getattr(model, "temporal_encoder", None)
         if sync_bn and enc is not None:
             enc.stats_all_reduce = self._stats_all_reduce
+            enc.stats_all_reduce_start = self._stats_all_reduce_start
             enc.stats_world_size = self.world
             enc.stats_global_rows = self._global_rows
         fm = getattr(model, "fusion_module", None)
@@ -263,6 +264,14 @@ class DataParallel:
         if self._rows_local == 0:
             t.zero_()                      # a stand-in batch contributes nothing to the global statistics
         self.transport.all_reduce(t, "sum")
+
+    def _stats_all_reduce_start(self, t: torch.Tensor):
+        """The same reduction, started now and waited for later (backward pass: the weight gradient of the layer
+        above does not depend on it and runs in between)."""
+        if self._rows_local == 0:
+            t.zero_()
+        work = self.transport.all_reduce(t, "sum", async_op=True)
+        return work if work is not None else _Done()
 
     # ------------------------------------------------------------------ memory bank
     def _gather_bank_rows(self, rows: torch.Tensor) -> torch.Tensor:
