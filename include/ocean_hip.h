@@ -54,6 +54,13 @@ int ocean_conv_gemm_f32(const float* A, int lda, const float* B, int ldb, float*
                         int a_kmajor, int b_kn, int taps, int T, int shift0, int shift_step, long tap_stride_b,
                         long tap_stride_c, int split_k, void* stream);
 
+/* Backward of y[M,N] = x[M,K] . W[N,K]^T + b: dW[N,K] += dy^T . x, db[N] += column sums of dy (NULL: skipped),
+ * dx[M,K] = dy . W (accumulate_dx: +=).  A small layer's two products share one launch; dx must not overlap x, dy or
+ * the gradients.  Replaces autograd's backward of every nn.Linear on the model path (e.g. the head,
+ * ocean/models/ocean_model.py:112-121); exported for kernel-level tests. */
+int ocean_linear_bwd_f32(const float* x, int ldx, const float* dy, int lddy, const float* W, float* dW, float* db, float* dx,
+                         int lddx, int M, int N, int K, int accumulate_dx, void* stream);
+
 /* out[G,C] = mean over the middle axis of a[G,n,C].  Replaces torch.mean(logs, dim=1) for
  * [B,L,768] log embeddings (ocean/models/ocean_model.py:179-181). */
 int ocean_mean_mid_f32(const float* a, float* out, int G, int n, int C, void* stream);

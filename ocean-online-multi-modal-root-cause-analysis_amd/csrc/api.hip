@@ -27,6 +27,13 @@ int ocean_conv_gemm_f32(const float* A, int lda, const float* B, int ldb, float*
   return ocean_launch_gemm(p, (hipStream_t)stream);
 }
 
+int ocean_linear_bwd_f32(const float* x, int ldx, const float* dy, int lddy, const float* W, float* dW, float* db, float* dx, int lddx,
+                         int M, int N, int K, int accumulate_dx, void* stream) {
+  if (!x || !dy || !W || !dW || !dx) return OCEAN_ERR_NULL;
+  if (M <= 0 || N <= 0 || K <= 0) return OCEAN_ERR_BAD_SHAPE;
+  return linear_bwd_pair(x, ldx, dy, lddy, W, dW, db, dx, lddx, M, N, K, accumulate_dx, (hipStream_t)stream);
+}
+
 int ocean_mean_mid_f32(const float* a, float* out, int G, int n, int C, void* stream) {
   if (!a || !out) return OCEAN_ERR_NULL;
   if (G <= 0 || n <= 0 || C <= 0) return OCEAN_ERR_BAD_SHAPE;

@@ -143,6 +143,9 @@ int ocean_launch_gemm_batch(const GemmP* ps, int n, hipStream_t stream);
 // the kernel for outputs of few tiles (gemm_skinny.hip): ocean_launch_gemm_batch sends eligible batches there
 bool ocean_gemm_skinny_applies(const GemmBatch& b);
 int ocean_launch_gemm_skinny(const GemmBatch& b, hipStream_t stream);
+// a linear layer's weight-gradient problems `w` and data-gradient problems `d` (same dy, independent outputs): one launch
+// when both are few-tile work, else ocean_launch_gemm_batch(w) then ocean_launch_gemm_batch(d)
+int ocean_launch_gemm_pair(const GemmP* w, int nw, const GemmP* d, int nd, hipStream_t stream);
 
 // the kernel for large products of two k-contiguous operands with full tiles (gemm_nt.hip), likewise
 bool ocean_gemm_nt_applies(const GemmBatch& b);

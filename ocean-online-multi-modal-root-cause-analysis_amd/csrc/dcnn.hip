@@ -718,8 +718,9 @@ int dcnn_bwd_impl(const ocean_dcnn_shape* s, const float* x, float* const* param
       if (!part_a) continue;
       OCEAN_TRY(zero_f32(wb + pl.bstats[0], pl.bwd_total - pl.bstats[0], st));   // bstats + packed weight grads
       // output projection
-      OCEAN_TRY(linear_bwd_weight(dout, s->out_dim, wf + pl.pooled, Cl, grads[pi_out(L, 0)], s->B, s->out_dim, Cl, st, grads[pi_out(L, 1)]));   // + bias gradient (column sums of the same operand)
-      OCEAN_TRY(linear_bwd_data(dout, s->out_dim, params[pi_out(L, 0)], wb + pl.dpool, Cl, s->B, s->out_dim, Cl, 0, st));
+      // weight, bias (column sums of the same operand) and data gradients of the output projection
+      OCEAN_TRY(linear_bwd_pair(wf + pl.pooled, Cl, dout, s->out_dim, params[pi_out(L, 0)], grads[pi_out(L, 0)], grads[pi_out(L, 1)], wb + pl.dpool, Cl,
+                                s->B, s->out_dim, Cl, 0, st));
       OCEAN_TRY(reduce(pl.nbn - 1));
       OCEAN_TRY(reduce_finish(pl.nbn - 1));
       continue;

@@ -275,7 +275,8 @@ DropoutP site(const ocean_fusion_shape* s, int id) {
 
 int lin_bwd(const float* x, int ldx, const float* dy, int lddy, int M, int N, int K, const float* W, float* dW, float* db,
             float* dx, int lddx, int accumulate, hipStream_t st, const Epi* dx_epi = nullptr) {
-  if (dW) OCEAN_TRY(linear_bwd_weight(dy, lddy, x, ldx, dW, M, N, K, st, db));   // db rides along as the column sums of dy
+  if (dW && dx) return linear_bwd_pair(x, ldx, dy, lddy, W, dW, db, dx, lddx, M, N, K, accumulate, st, dx_epi);   // db rides along as the column sums of dy
+  if (dW) OCEAN_TRY(linear_bwd_weight(dy, lddy, x, ldx, dW, M, N, K, st, db));
   else if (db) OCEAN_TRY(colsum_add(dy, lddy, M, N, db, st));
   if (dx) OCEAN_TRY(linear_bwd_data(dy, lddy, W, dx, lddx, M, N, K, accumulate, st, dx_epi));
   return OCEAN_OK;

@@ -1359,8 +1359,8 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
   const long rows = pl.rows;
   const int Cl = pl.out_dim[Lr - 1];
   // output projection
-  OCEAN_TRY(linear_bwd_weight(dout, D, wf + pl.pooled, Cl, grads[pg_out(Lr, 0)], pl.P, D, Cl, st, grads[pg_out(Lr, 1)]));   // + bias gradient (column sums of the same operand)
-  OCEAN_TRY(linear_bwd_data(dout, D, params[pg_out(Lr, 0)], wb + pl.dpool, Cl, pl.P, D, Cl, 0, st));
+  // weight, bias (column sums of the same operand) and data gradients of the output projection
+  OCEAN_TRY(linear_bwd_pair(wf + pl.pooled, Cl, dout, D, params[pg_out(Lr, 0)], grads[pg_out(Lr, 0)], grads[pg_out(Lr, 1)], wb + pl.dpool, Cl, pl.P, D, Cl, 0, st));
   const bool share0 = s->R > 1 && fast_edges(pl);
   float* dx0 = wb + pl.dx0;
   for (int l = Lr - 1; l >= 0; --l) {

@@ -18,22 +18,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kUnroll = 4;          // 8-deep reduction steps loaded together (4 x 2 x float4 = 32 registers)
+constexpr int kSkinnyUnroll = 4;    // 8-deep reduction steps loaded together (4 x 2 x float4 = 32 registers)
+constexpr int kPairUnroll = 2;      // the same inside gemm_pair_kernel, whose 1024-thread blocks leave a thread 128 registers
 
-template <bool BKN>
-__global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmBatch batch) {
-  const GemmP& p = batch.g[blockIdx.y];
+// One 32x32 output tile by one group of 256 threads (tid = 0..255 inside the group; `part` is the group's own four
+// partial tiles).  Every thread of the block must call it, active or not: it holds a block-wide barrier.  An inactive
+// group (its tile index is past the problem's last tile) loads and stores nothing.
+template <bool BKN, int kUnroll>
+__device__ __forceinline__ void skinny_tile(const GemmP& p, const int tile, const int tid, float (*part)[32][33]) {
   const int tiles_n = (p.N + 31) / 32, tiles_m = (p.M + 31) / 32;
-  if ((int)blockIdx.x >= tiles_m * tiles_n) return;              // the grid is sized for the largest problem of the batch
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const bool active = tile < tiles_m * tiles_n;
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
   const int m0 = tile_m * 32, n0 = tile_n * 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 31, h = lane >> 5;
 
   // this wave's share of the reduction, in whole 8-deep steps
   const int steps = (p.K + 7) / 8;
   const int per = (steps + 3) / 4;
-  const int s_begin = wave * per, s_end = min(steps, s_begin + per);
+  const int s_begin = wave * per, s_end = active ? min(steps, s_begin + per) : s_begin;
 
   constexpr unsigned kOob = 0x80000000u;                         // out-of-range offset: a buffer load returns zeros
   const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7FFFFFF0, 0x00020000);
@@ -91,10 +94,10 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmBatch b
   }
 
   // partial tiles -> LDS; acc register r of lane (lm, h) is C[(r&3) + 8*(r>>2) + 4*h][lm]
-  __shared__ float part[4][32][33];
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * h][lm] = acc[r];
   __syncthreads();
+  if (!active) return;
 
   const DropoutP drop = dropout_resolve(p.drop);
   const int col = n0 + (tid & 31);
@@ -117,6 +120,14 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmBatch b
   }
 }
 
+template <bool BKN>
+__global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmBatch batch) {
+  const GemmP& p = batch.g[blockIdx.y];
+  if ((int)blockIdx.x >= ((p.N + 31) / 32) * ((p.M + 31) / 32)) return;   // the grid is sized for the largest problem of the batch
+  __shared__ float part[4][32][33];
+  skinny_tile<BKN, kSkinnyUnroll>(p, blockIdx.x, threadIdx.x, part);
+}
+
 // Row reductions with a small output (a linear layer's weight gradient C[M][N] += sum_k A[k][m] B[k][n] over a few
 // thousand rows, optionally the column sums of A on the side: its bias gradient).  Such a launch is bound by memory
 // round trips and by the cost of atomic adds, not by arithmetic.  A block of SIXTEEN waves owns one 32x32 output tile
@@ -129,19 +140,20 @@ __global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmBatch b
 constexpr int kRowsWaves = 16;
 constexpr int kRedUnroll = 8;          // MFMA steps whose 2 x 8 loads are requested together (two such groups in flight; 12 would spill at 16 waves per block)
 
-__global__ __launch_bounds__(kRowsWaves * 64) void gemm_skinny_rows_kernel(const GemmBatch batch, const int plain) {
-  const GemmP& p = batch.g[blockIdx.y];
-  const int tiles_n = (p.N + 31) / 32, tiles_m = (p.M + 31) / 32;
-  if ((int)blockIdx.x >= tiles_m * tiles_n) return;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+// One 32x32 output tile (index `tile`, which the caller has checked) by a block of sixteen waves, over row slice
+// `slice` of `nslices`.
+__device__ __forceinline__ void rows_tile(const GemmP& p, const int tile, const int slice, const int nslices, const int plain,
+                                          float (*part)[32][33], float (*csum)[32]) {
+  const int tiles_n = (p.N + 31) / 32;
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
   const int m0 = tile_m * 32, n0 = tile_n * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 31, h = lane >> 5;
 
   // rows of this block's slice, then of this wave's share of it (whole MFMA steps of two rows)
   const int steps = (p.K + 1) / 2;
-  const int per_block = (steps + (int)gridDim.z - 1) / (int)gridDim.z;
-  const int b_begin = (int)blockIdx.z * per_block, b_end = min(steps, b_begin + per_block);
+  const int per_block = (steps + nslices - 1) / nslices;
+  const int b_begin = slice * per_block, b_end = min(steps, b_begin + per_block);
   const int per_wave = (per_block + kRowsWaves - 1) / kRowsWaves;
   const int s_begin = b_begin + wave * per_wave, s_end = min(b_end, s_begin + per_wave);
 
@@ -176,8 +188,6 @@ __global__ __launch_bounds__(kRowsWaves * 64) void gemm_skinny_rows_kernel(const
     for (int u = 0; u < kRedUnroll; ++u) { asum += a1[u]; acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc, 0, 0, 0); }
   }
 
-  __shared__ float part[kRowsWaves][32][33];
-  __shared__ float csum[kRowsWaves][32];
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * h][lm] = acc[r];
   asum += __shfl_xor(asum, 32);
@@ -198,6 +208,36 @@ __global__ __launch_bounds__(kRowsWaves * 64) void gemm_skinny_rows_kernel(const
     for (int w = 0; w < kRowsWaves; ++w) v += csum[w][tid];
     if (plain) p.a_colsum[m0 + tid] += v;
     else unsafeAtomicAdd(p.a_colsum + m0 + tid, v);
+  }
+}
+
+__global__ __launch_bounds__(kRowsWaves * 64) void gemm_skinny_rows_kernel(const GemmBatch batch, const int plain) {
+  const GemmP& p = batch.g[blockIdx.y];
+  if ((int)blockIdx.x >= ((p.N + 31) / 32) * ((p.M + 31) / 32)) return;
+  __shared__ float part[kRowsWaves][32][33];
+  __shared__ float csum[kRowsWaves][32];
+  rows_tile(p, blockIdx.x, blockIdx.z, gridDim.z, plain, part, csum);
+}
+
+// A linear layer's two gradients in ONE launch: they read the same dy and are independent of each other, and each alone
+// is a launch of a few microseconds that leaves most of the chip idle.  Blocks with blockIdx.z < wsplit take the weight
+// gradient's role (rows_tile over batch `wb`, row slice blockIdx.z), blocks with blockIdx.z == wsplit the data gradient's
+// (batch `db`: four groups of 256 threads, a tile each).  The grid spans the larger of the two roles in x and y; a block
+// outside its role's range leaves at once.
+__global__ __launch_bounds__(kRowsWaves * 64) void gemm_pair_kernel(const GemmBatch wb, const GemmBatch db, const int wsplit, const int plain) {
+  __shared__ float part[kRowsWaves][32][33];
+  __shared__ float csum[kRowsWaves][32];
+  if ((int)blockIdx.z < wsplit) {
+    if ((int)blockIdx.y >= wb.n) return;
+    const GemmP& p = wb.g[blockIdx.y];
+    if ((int)blockIdx.x >= ((p.N + 31) / 32) * ((p.M + 31) / 32)) return;
+    rows_tile(p, blockIdx.x, blockIdx.z, wsplit, plain, part, csum);
+  } else {
+    if ((int)blockIdx.y >= db.n) return;
+    const GemmP& p = db.g[blockIdx.y];
+    if ((int)blockIdx.x * 4 >= ((p.N + 31) / 32) * ((p.M + 31) / 32)) return;
+    const int group = threadIdx.x >> 8;
+    skinny_tile<true, kPairUnroll>(p, blockIdx.x * 4 + group, threadIdx.x & 255, part + 4 * group);
   }
 }
 
@@ -247,17 +287,19 @@ bool ocean_gemm_skinny_applies(const GemmBatch& b) {
   return blocks64 < 256 && tiles32 <= 2048;
 }
 
-static int launch_skinny_rows(const GemmBatch& b, hipStream_t stream) {
-  int tiles = 0;
+// Grid of a row-reduction batch: the most tiles of any problem, the row slices, and whether the block of a tile may add
+// into C with plain loads and stores.
+struct RowsGrid { int tiles, split, plain; double flops, bytes; };
+static RowsGrid rows_grid(const GemmBatch& b) {
+  RowsGrid r{0, 1, 0, 0.0, 0.0};
   long all_tiles = 0;
-  double flops = 0.0, bytes = 0.0;
   for (int q = 0; q < b.n; ++q) {
     const GemmP& p = b.g[q];
     const int t = ceil_div(p.M, 32) * ceil_div(p.N, 32);
-    if (t > tiles) tiles = t;
+    if (t > r.tiles) r.tiles = t;
     all_tiles += t;
-    flops += 2.0 * p.M * p.N * (double)p.K;
-    bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+    r.flops += 2.0 * p.M * p.N * (double)p.K;
+    r.bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
   }
   // One block per tile unless that leaves most of the chip idle: then the rows are sliced over blocks too, down to
   // one request round per wave (2 x kRedUnroll rows), the slices adding atomically.
@@ -274,19 +316,81 @@ static int launch_skinny_rows(const GemmBatch& b, hipStream_t stream) {
     if (split > most) split = most;
     if (split < 1) split = 1;
   }
-  void* tok = nullptr;
-  if (ocean_prof_on()) ocean_prof_begin("gemm_skinny_rows_kernel", flops, bytes, stream, &tok);
+  r.split = split;
   // plain (non-atomic) accumulation needs every output element to have one writer in this launch: one slice, and no
   // two problems of the batch whose outputs (or bias-gradient vectors) overlap
   bool plain = split == 1;
   for (int q = 0; q < b.n && plain; ++q)
-    for (int r = q + 1; r < b.n && plain; ++r) {
-      const GemmP &x = b.g[q], &y = b.g[r];
+    for (int r2 = q + 1; r2 < b.n && plain; ++r2) {
+      const GemmP &x = b.g[q], &y = b.g[r2];
       const float *x0 = x.C, *x1 = x.C + (size_t)(x.M - 1) * x.ldc + x.N, *y0 = y.C, *y1 = y.C + (size_t)(y.M - 1) * y.ldc + y.N;
       if (x0 < y1 && y0 < x1) plain = false;
       if (x.a_colsum && y.a_colsum && x.a_colsum < y.a_colsum + y.M && y.a_colsum < x.a_colsum + x.M) plain = false;
     }
-  hipLaunchKernelGGL(gemm_skinny_rows_kernel, dim3(tiles, b.n, split), dim3(kRowsWaves * 64), 0, stream, b, plain ? 1 : 0);
+  r.plain = plain ? 1 : 0;
+  return r;
+}
+
+static int launch_skinny_rows(const GemmBatch& b, hipStream_t stream) {
+  const RowsGrid r = rows_grid(b);
+  void* tok = nullptr;
+  if (ocean_prof_on()) ocean_prof_begin("gemm_skinny_rows_kernel", r.flops, r.bytes, stream, &tok);
+  hipLaunchKernelGGL(gemm_skinny_rows_kernel, dim3(r.tiles, b.n, r.split), dim3(kRowsWaves * 64), 0, stream, b, r.plain);
+  ocean_prof_end(tok, stream);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+// [lo, hi) of the floats a row-major operand of `rows` rows of `cols` floats, `ld` apart, occupies
+static inline bool spans_overlap(const float* a, long rows_a, long ld_a, long cols_a, const float* b, long rows_b, long ld_b, long cols_b) {
+  const float *a1 = a + (rows_a - 1) * ld_a + cols_a, *b1 = b + (rows_b - 1) * ld_b + cols_b;
+  return a < b1 && b < a1;
+}
+
+// Weight-gradient problems `w` (row reductions, a_kmajor && b_kn) and data-gradient problems `d` (b_kn) of the same
+// layers: one launch of gemm_pair_kernel when both are work for the few-tile kernels and nothing one role writes is read
+// or written by the other; otherwise the two ordinary launches, weight gradients first.
+int ocean_launch_gemm_pair(const GemmP* w, int nw, const GemmP* d, int nd, hipStream_t stream) {
+  static const bool off = getenv("OCEAN_GEMM_NO_PAIR") != nullptr;         // measurement switch
+  bool pair = !off && nw >= 1 && nd >= 1 && nw <= kGemmBatchMax && nd <= kGemmBatchMax;
+  GemmBatch wb, db;
+  if (pair) {
+    wb.n = nw; db.n = nd;
+    for (int q = 0; q < nw; ++q) wb.g[q] = w[q];
+    for (int q = 0; q < nd; ++q) db.g[q] = d[q];
+    for (int q = 0; q < nw && pair; ++q) pair = w[q].a_kmajor && w[q].b_kn && w[q].M > 0 && w[q].N > 0 && w[q].K > 0 && w[q].A && w[q].B && w[q].C;
+    for (int q = 0; q < nd && pair; ++q) pair = !d[q].a_kmajor && d[q].b_kn && d[q].M > 0 && d[q].N > 0 && d[q].K > 0 && d[q].A && d[q].B && d[q].C;
+    pair = pair && wb.g[0].K <= 8192 && ocean_gemm_skinny_applies(wb) && ocean_gemm_skinny_applies(db);
+    for (int q = 0; q < nd && pair; ++q)
+      for (int r = 0; r < nw && pair; ++r) {
+        const GemmP &x = d[q], &y = w[r];
+        // the data gradient's output against the weight gradient's operands and outputs
+        if (spans_overlap(x.C, x.M, x.ldc, x.N, y.A, y.K, y.lda, y.M) || spans_overlap(x.C, x.M, x.ldc, x.N, y.B, y.K, y.ldb, y.N) ||
+            spans_overlap(x.C, x.M, x.ldc, x.N, y.C, y.M, y.ldc, y.N) || (y.a_colsum && spans_overlap(x.C, x.M, x.ldc, x.N, y.a_colsum, 1, 0, y.M)))
+          pair = false;
+        // the weight gradient's outputs against the data gradient's operands
+        if (spans_overlap(y.C, y.M, y.ldc, y.N, x.A, x.M, x.lda, x.K) || spans_overlap(y.C, y.M, y.ldc, y.N, x.B, x.K, x.ldb, x.N)) pair = false;
+      }
+  }
+  if (!pair) {
+    if (nw > 0) OCEAN_TRY(ocean_launch_gemm_batch(w, nw, stream));
+    if (nd > 0) OCEAN_TRY(ocean_launch_gemm_batch(d, nd, stream));
+    return OCEAN_OK;
+  }
+  const RowsGrid r = rows_grid(wb);
+  int dblocks = 0;
+  double flops = r.flops, bytes = r.bytes;
+  for (int q = 0; q < nd; ++q) {
+    const GemmP& p = d[q];
+    const int t = ceil_div(ceil_div(p.M, 32) * ceil_div(p.N, 32), 4);
+    if (t > dblocks) dblocks = t;
+    flops += 2.0 * p.M * p.N * (double)p.K;
+    bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+  }
+  void* tok = nullptr;
+  if (ocean_prof_on()) ocean_prof_begin("gemm_pair_kernel", flops, bytes, stream, &tok);
+  hipLaunchKernelGGL(gemm_pair_kernel, dim3(r.tiles > dblocks ? r.tiles : dblocks, nw > nd ? nw : nd, r.split + 1), dim3(kRowsWaves * 64), 0,
+                     stream, wb, db, r.split, r.plain);
   ocean_prof_end(tok, stream);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;

@@ -604,16 +604,15 @@ int ocean_head_bwd(const ocean_head_shape* s, const float* x, float* const* P_, 
   float* dl = wb; float* d1 = wb + al4((size_t)B * s->S); float* d2 = d1 + al4((size_t)B * s->h1);
   hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(egrid((long)B * s->S)), dim3(256), 0, st, dlogits, dprobs, probs, dl, (long)B * s->S);
   OCEAN_LAUNCH_CHECK();
-  OCEAN_TRY(linear_bwd_weight(dl, s->S, a2, s->h2, G_[4], B, s->S, s->h2, st, G_[5]));   // + bias gradient (column sums of the same operand)
   const DropoutP dr0 = head_site(s, 0), dr1 = head_site(s, 1);
-  Epi e0, e1;      // dropout and ReLU backward on the way out of the dgrad GEMMs
+  Epi e0, e1;      // dropout and ReLU backward on the way out of the data gradients
   e0.drop = &dr0; e0.relu_mask = a1; e0.ld_mask = s->h1;
   e1.drop = &dr1; e1.relu_mask = a2; e1.ld_mask = s->h2;
-  OCEAN_TRY(linear_bwd_data(dl, s->S, P_[4], d2, s->h2, B, s->S, s->h2, 0, st, &e1));
-  OCEAN_TRY(linear_bwd_weight(d2, s->h2, a1, s->h1, G_[2], B, s->h2, s->h1, st, G_[3]));   // + bias gradient (column sums of the same operand)
-  OCEAN_TRY(linear_bwd_data(d2, s->h2, P_[2], d1, s->h1, B, s->h2, s->h1, 0, st, &e0));
-  OCEAN_TRY(linear_bwd_weight(d1, s->h1, x, s->E, G_[0], B, s->h1, s->E, st, G_[1]));   // + bias gradient (column sums of the same operand)
-  if (dx) OCEAN_TRY(linear_bwd_data(d1, s->h1, P_[0], dx, s->E, B, s->h1, s->E, 0, st));
+  // per layer: weight gradient, bias gradient (column sums of the same operand) and data gradient
+  OCEAN_TRY(linear_bwd_pair(a2, s->h2, dl, s->S, P_[4], G_[4], G_[5], d2, s->h2, B, s->S, s->h2, 0, st, &e1));
+  OCEAN_TRY(linear_bwd_pair(a1, s->h1, d2, s->h2, P_[2], G_[2], G_[3], d1, s->h1, B, s->h2, s->h1, 0, st, &e0));
+  if (dx) return linear_bwd_pair(x, s->E, d1, s->h1, P_[0], G_[0], G_[1], dx, s->E, B, s->h1, s->E, 0, st);
+  OCEAN_TRY(linear_bwd_weight(d1, s->h1, x, s->E, G_[0], B, s->h1, s->E, st, G_[1]));
   return OCEAN_OK;
 }
 

@@ -14,6 +14,10 @@ int linear_bwd_data(const float* dy, int lddy, const float* W, float* dx, int ld
 // dW[N,K] += dy[M,N]^T . x[M,K]                          (nn.Linear weight gradient, atomic accumulate)
 int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float* dW,
                       int M, int N, int K, hipStream_t s, float* db = nullptr);
+// both gradients of one layer (dW += dy^T x, db += column sums of dy when non-null, dx (+)= dy W): one launch when the
+// layer is small enough for the few-tile kernels, else the two calls above in that order
+int linear_bwd_pair(const float* x, int ldx, const float* dy, int lddy, const float* W, float* dW, float* db, float* dx, int lddx,
+                    int M, int N, int K, int accumulate, hipStream_t s, const Epi* e = nullptr);
 // Batched forms: up to kGemmBatchMax independent layers (the three modality branches) per launch.
 struct LinFwd { const float* x; int ldx; const float* W; const float* b; float* y; int ldy; int M, N, K; };
 // drop: one dropout site over the entries' outputs stacked row-wise (entry q covers rows [q*M, (q+1)*M))

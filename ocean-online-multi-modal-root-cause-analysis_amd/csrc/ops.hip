@@ -49,40 +49,57 @@ int linear_fwd_batch(const LinFwd* l, int n, int relu, hipStream_t s, const Drop
   return ocean_launch_gemm_batch(g, n, s);
 }
 
+int linear_bwd_pair(const float* x, int ldx, const float* dy, int lddy, const float* W, float* dW, float* db, float* dx, int lddx,
+                    int M, int N, int K, int accumulate, hipStream_t s, const Epi* e) {
+  GemmP w = gemm_defaults();
+  w.a_colsum = db;
+  w.A = dy; w.lda = lddy; w.a_kmajor = 1; w.B = x; w.ldb = ldx; w.b_kn = 1; w.C = dW; w.ldc = K;
+  w.M = N; w.N = K; w.K = M; w.split_k = 0;
+  GemmP d = gemm_defaults();
+  d.A = dy; d.lda = lddy; d.B = W; d.ldb = K; d.b_kn = 1; d.C = dx; d.ldc = lddx;
+  d.M = M; d.N = K; d.K = N;
+  if (accumulate) { d.R = dx; d.ldr = lddx; }
+  apply_epi(d, e);
+  return ocean_launch_gemm_pair(&w, 1, &d, 1, s);
+}
+
 int linear_bwd_batch(const LinBwd* l, int n, int accumulate_dx, hipStream_t s, const DropoutP* dx_drop, int drop_group,
                      const float* const* relu_masks, int ld_mask) {
   if (n < 1 || n > kGemmBatchMax) return OCEAN_ERR_BAD_SHAPE;
-  GemmP g[kGemmBatchMax];
-  int k = 0;
+  GemmP gw[kGemmBatchMax], gd[kGemmBatchMax];
+  int kw = 0, kd = 0;
   for (int q = 0; q < n; ++q) {
     if (!l[q].dW) continue;
-    g[k] = gemm_defaults();
-    g[k].A = l[q].dy; g[k].lda = l[q].lddy; g[k].a_kmajor = 1; g[k].B = l[q].x; g[k].ldb = l[q].ldx; g[k].b_kn = 1;
-    g[k].C = l[q].dW; g[k].ldc = l[q].K; g[k].M = l[q].N; g[k].N = l[q].K; g[k].K = l[q].M; g[k].split_k = 0;
-    g[k].a_colsum = l[q].db;       // the bias gradient rides along with the weight gradient
-    ++k;
+    GemmP& g = gw[kw++];
+    g = gemm_defaults();
+    g.A = l[q].dy; g.lda = l[q].lddy; g.a_kmajor = 1; g.B = l[q].x; g.ldb = l[q].ldx; g.b_kn = 1;
+    g.C = l[q].dW; g.ldc = l[q].K; g.M = l[q].N; g.N = l[q].K; g.K = l[q].M; g.split_k = 0;
+    g.a_colsum = l[q].db;       // the bias gradient rides along with the weight gradient
   }
-  if (k > 0) OCEAN_TRY(ocean_launch_gemm_batch(g, k, s));
+  for (int q = 0; q < n; ++q) {
+    if (!l[q].dx) continue;
+    GemmP& g = gd[kd++];
+    g = gemm_defaults();
+    g.A = l[q].dy; g.lda = l[q].lddy; g.B = l[q].W; g.ldb = l[q].K; g.b_kn = 1; g.C = l[q].dx; g.ldc = l[q].lddx;
+    g.M = l[q].M; g.N = l[q].K; g.K = l[q].N;
+    if (accumulate_dx) { g.R = l[q].dx; g.ldr = l[q].lddx; }
+    if (dx_drop) { g.drop = *dx_drop; g.drop_group = drop_group; g.drop_row0 = q * l[q].M; }
+    if (relu_masks) { g.relu_mask = relu_masks[q]; g.ld_mask = ld_mask; }
+  }
+  // reductions of different lengths cannot share a weight-gradient launch, nor can the pair launch take them
+  bool same_rows = true;
+  for (int q = 1; q < kw; ++q) same_rows = same_rows && gw[q].K == gw[0].K;
+  if (kw > 0 && kd > 0 && same_rows) OCEAN_TRY(ocean_launch_gemm_pair(gw, kw, gd, kd, s));
+  else if (kw > 0) OCEAN_TRY(ocean_launch_gemm_batch(gw, kw, s));
   ColSum c[kGemmBatchMax];
-  k = 0;
+  int k = 0;
   for (int q = 0; q < n; ++q) {
     if (!l[q].db || l[q].dW) continue;
     c[k].a = l[q].dy; c[k].lda = l[q].lddy; c[k].M = l[q].M; c[k].N = l[q].N; c[k].out = l[q].db;
     ++k;
   }
   if (k > 0) OCEAN_TRY(colsum_add_batch(c, k, s));
-  k = 0;
-  for (int q = 0; q < n; ++q) {
-    if (!l[q].dx) continue;
-    g[k] = gemm_defaults();
-    g[k].A = l[q].dy; g[k].lda = l[q].lddy; g[k].B = l[q].W; g[k].ldb = l[q].K; g[k].b_kn = 1; g[k].C = l[q].dx; g[k].ldc = l[q].lddx;
-    g[k].M = l[q].M; g[k].N = l[q].K; g[k].K = l[q].N;
-    if (accumulate_dx) { g[k].R = l[q].dx; g[k].ldr = l[q].lddx; }
-    if (dx_drop) { g[k].drop = *dx_drop; g[k].drop_group = drop_group; g[k].drop_row0 = q * l[q].M; }
-    if (relu_masks) { g[k].relu_mask = relu_masks[q]; g[k].ld_mask = ld_mask; }
-    ++k;
-  }
-  if (k > 0) OCEAN_TRY(ocean_launch_gemm_batch(g, k, s));
+  if (kd > 0 && !(kw > 0 && same_rows)) OCEAN_TRY(ocean_launch_gemm_batch(gd, kd, s));
   return OCEAN_OK;
 }
 

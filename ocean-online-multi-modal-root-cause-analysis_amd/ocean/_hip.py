@@ -136,6 +136,7 @@ def _declare_rest(lib) -> None:
     sig("ocean_bce_fwd", c_int, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_bce_bwd", c_int, vp, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_conv_gemm_f32", c_int, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_int, vp)
+    sig("ocean_linear_bwd_f32", c_int, vp, c_int, vp, c_int, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp)
     sig("ocean_mean_mid_f32", c_int, vp, vp, c_int, c_int, c_int, vp)
     sig("ocean_mse_fwd", c_int, vp, vp, c_long, vp, vp)
     sig("ocean_mse_bwd", c_int, vp, vp, vp, c_long, vp, vp)
@@ -328,6 +329,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
                               ldr or ldc, int(relu), stream())
     check(st, "ocean_gemm_f32")
     return out
+
+
+def linear_bwd(x: torch.Tensor, dy: torch.Tensor, w: torch.Tensor, dw: torch.Tensor, db, dx: torch.Tensor, M: int,
+               N: int, K: int, *, ldx=None, lddy=None, lddx=None, accumulate_dx=False) -> None:
+    """Both gradients of one linear layer (tests and small glue): see ocean_linear_bwd_f32."""
+    st = lib().ocean_linear_bwd_f32(dev_ptr(x, "x"), ldx or K, dev_ptr(dy, "dy"), lddy or N, dev_ptr(w, "W"), dev_ptr(dw, "dW"),
+                                    dev_ptr(db, "db"), dev_ptr(dx, "dx"), lddx or K, M, N, K, int(accumulate_dx), stream())
+    check(st, "ocean_linear_bwd_f32")
 
 
 def clear_last_error() -> int:

@@ -197,3 +197,40 @@ def test_large_kernels_with_padded_leading_dimensions():
     torch.cuda.synchronize()
     _close(d, (1.0 + y.double().t() @ x.double()).cpu(), 5e-5)
     assert bool((dbig[:, :4] == 1).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(3072, 256, 256), (1024, 768, 256), (1024, 128, 256), (1024, 12, 64), (1000, 100, 36), (333, 64, 512),
+                                   (96, 32, 32), (8192, 64, 64), (20000, 64, 64), (1024, 7, 64), (64, 768, 768)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_linear_layer_gradient_pair(M, N, K, accumulate):
+    """dW += dy^T x, db += column sums of dy and dx (+)= dy W of one layer: shapes whose two products share one
+    launch (both of few tiles, the reduction of the weight gradient at most 8192 rows), shapes that fall back to two
+    launches (N % 4 != 0, M > 8192), ragged tiles, and dx accumulating onto earlier contents."""
+    from ocean import _hip
+    x, dy, w = _rand(M, K, seed=1), _rand(M, N, seed=2), _rand(N, K, seed=3)
+    dw0, db0, dx0 = _rand(N, K, seed=4), _rand(N, seed=5), _rand(M, K, seed=6)
+    dw, db, dx = dw0.cuda(), db0.cuda(), dx0.cuda()
+    _hip.linear_bwd(x.cuda(), dy.cuda(), w.cuda(), dw, db, dx, M, N, K, accumulate_dx=accumulate)
+    _close(dw, dw0.double() + dy.double().t() @ x.double(), tol=4e-5)
+    _close(db, db0.double() + dy.double().sum(0), tol=4e-5)
+    _close(dx, (dx0.double() if accumulate else 0) + dy.double() @ w.double())
+    # no bias gradient, and padded leading dimensions
+    xp, dyp, dxp = torch.zeros(M, K + 4), torch.zeros(M, N + 8), torch.full((M, K + 12), 7.0)
+    xp[:, :K], dyp[:, :N] = x, dy
+    dw, dxd = dw0.cuda(), dxp.cuda()
+    _hip.linear_bwd(xp.cuda(), dyp.cuda(), w.cuda(), dw, None, dxd, M, N, K, ldx=K + 4, lddy=N + 8, lddx=K + 12)
+    _close(dw, dw0.double() + dy.double().t() @ x.double(), tol=4e-5)
+    _close(dxd[:, :K], dy.double() @ w.double())
+    assert bool((dxd[:, K:] == 7.0).all())
+
+
+def test_linear_layer_gradient_pair_refuses_overlap():
+    """dx aliasing x: the two products must not share a launch (the data gradient would overwrite the weight gradient's
+    operand while it is read); the result must equal weight gradient first, data gradient second."""
+    from ocean import _hip
+    M, N, K = 1024, 64, 64
+    x, dy, w = _rand(M, K, seed=1), _rand(M, N, seed=2), _rand(N, K, seed=3)
+    buf, dw = x.cuda(), torch.zeros(N, K, device="cuda")
+    _hip.linear_bwd(buf, dy.cuda(), w.cuda(), dw, None, buf, M, N, K)
+    _close(dw, dy.double().t() @ x.double(), tol=4e-5)
+    _close(buf, dy.double() @ w.double())
