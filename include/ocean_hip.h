@@ -307,6 +307,12 @@ int ocean_infonce3_bwd(const ocean_infonce3_shape* s, float* ws, float* ws_bwd, 
  * Keeping the pointer off the host lets the write sit in a captured HIP graph. */
 int ocean_bank_ring_write(float* bank, long long* ptr, const float* rows, int R, int K, int P, void* stream);
 
+/* out [n_perm, B] int64: n_perm independent uniform random permutations of 0..B-1 (B <= 4096; larger B returns
+ * OCEAN_ERR_UNSUPPORTED and the caller draws them itself), a function of seed (+ *seed_epoch, see ocean_dcnn_shape).
+ * Replaces torch.randperm(batch_size) in _compute_mutual_information (graph_fusion.py:494), one launch for the three
+ * modalities. */
+int ocean_draw_permutations(int n_perm, int B, uint64_t seed, const uint64_t* seed_epoch, long long* out, void* stream);
+
 /* MINE estimates of GraphFusionModule._compute_mutual_information (graph_fusion.py:475-501) for the three modalities:
  * mi[m] = mean_b f(cat(fused_b, X_{b,m})) - log(mean_b exp f(cat(fused_b, X_{perms[m][b],m})) + 1e-8),
  * f = Linear(E -> 1)(ReLU(Linear(2E -> E)(.))) with weights w0 [E, 2E], b0 [E], w1 [E], b1 [1].
@@ -337,6 +343,13 @@ int ocean_head_fwd(const ocean_head_shape* s, const float* x, float* const* para
 int ocean_head_bwd(const ocean_head_shape* s, const float* x, float* const* params, float* ws_fwd, float* ws_bwd,
                    size_t ws_bwd_floats, const float* probs, const float* d_logits /* or NULL */,
                    const float* d_probs /* or NULL */, float* const* grads, float* dx /* or NULL */, void* stream);
+
+/* OCEANModel.compute_loss's arithmetic on the device scalars (ocean_model.py:257-266), in its order of operations:
+ * out3 = [wp * pred + wc * (0 + c[0] + ... + c[n_c-1]),  pred,  0 + c[0] + ...]   (n_c <= 64; c may be NULL when 0).
+ * Backward: d_pred = wp * d_total, d_c[q] = wc * d_total + d_csum (a NULL upstream gradient counts as zero). */
+int ocean_loss_combine_fwd(const float* pred, const float* c, int n_c, float wp, float wc, float* out3, void* stream);
+int ocean_loss_combine_bwd(const float* d_total, const float* d_csum, int n_c, float wp, float wc, float* d_pred,
+                           float* d_c, void* stream);
 
 /* F.binary_cross_entropy(probs, targets, reduction='mean') (ocean_model.py:249-253; trainer.py:79).
  * *loss is ACCUMULATED; mean over mean_n elements (0 -> n). */

@@ -250,14 +250,14 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 // Row-reduction batches for gemm_skinny_rows_kernel: one tap, no row shifts, a reduction of at most 8192 rows (longer
 // ones fill the chip through the ring kernel's split, unless the output is a handful of tiles), at most 128 output tiles (with more, the 32x32 tiles' operand
 // re-reads from L2 cost more than the ring kernel's 64x64 tiles: 20-25 us measured at 384 tiles).
-static bool skinny_rows_applies(const GemmBatch& b) {
+static bool skinny_rows_applies(const GemmBatch& b, const int min_rows = 64) {
   static const bool off = getenv("OCEAN_GEMM_NO_SKINNY_ROWS") != nullptr;  // measurement switch
   if (off) return false;
   long tiles32 = 0;
   for (int q = 0; q < b.n; ++q) {
     const GemmP& p = b.g[q];
     if (!p.a_kmajor || !p.b_kn || p.taps != 1 || (p.T > 0 && p.shift0 != 0)) return false;
-    if (p.K != b.g[0].K || p.K < 64) return false;
+    if (p.K != b.g[0].K || p.K < min_rows) return false;
     if ((double)p.K * p.lda >= 5.0e8 || (double)p.K * p.ldb >= 5.0e8) return false;     // 32-bit byte offsets
     tiles32 += (long)ceil_div(p.M, 32) * ceil_div(p.N, 32);
   }
@@ -360,7 +360,9 @@ int ocean_launch_gemm_pair(const GemmP* w, int nw, const GemmP* d, int nd, hipSt
     for (int q = 0; q < nd; ++q) db.g[q] = d[q];
     for (int q = 0; q < nw && pair; ++q) pair = w[q].a_kmajor && w[q].b_kn && w[q].M > 0 && w[q].N > 0 && w[q].K > 0 && w[q].A && w[q].B && w[q].C;
     for (int q = 0; q < nd && pair; ++q) pair = !d[q].a_kmajor && d[q].b_kn && d[q].M > 0 && d[q].N > 0 && d[q].K > 0 && d[q].A && d[q].B && d[q].C;
-    pair = pair && wb.g[0].K <= 8192 && ocean_gemm_skinny_applies(wb) && ocean_gemm_skinny_applies(db);
+    // a reduction of a few rows (small batches) is no work for sixteen waves, but here it rides in a launch that is made anyway
+    static const bool skinny_off = getenv("OCEAN_GEMM_NO_SKINNY") != nullptr;
+    pair = pair && !skinny_off && wb.g[0].K <= 8192 && skinny_rows_applies(wb, 1) && ocean_gemm_skinny_applies(db);
     for (int q = 0; q < nd && pair; ++q)
       for (int r = 0; r < nw && pair; ++r) {
         const GemmP &x = d[q], &y = w[r];

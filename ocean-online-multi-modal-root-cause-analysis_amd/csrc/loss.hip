@@ -495,7 +495,7 @@ int ocean_infonce3_bwd(const ocean_infonce3_shape* s, float* ws, float* wb, size
 namespace {
 __global__ __launch_bounds__(256) void mi_rows_kernel(const float* __restrict__ U, const float* __restrict__ V, const long long* __restrict__ perms,
                                                       const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                      float* __restrict__ acc, int B, int E) {
+                                                      float* __restrict__ acc, float* __restrict__ mi, int B, int E) {
   __shared__ float red[2][kWaves];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, idx = blockIdx.x * kWaves + wave;
   float joint = 0.f, marg = 0.f;
@@ -518,18 +518,98 @@ __global__ __launch_bounds__(256) void mi_rows_kernel(const float* __restrict__ 
   __syncthreads();
   const int i0 = blockIdx.x * kWaves, i1 = min(i0 + kWaves, 3 * B) - 1;
   if (i0 / B == i1 / B) {           // the block's rows belong to one modality: one pair of adds
-    if (threadIdx.x < 2) unsafeAtomicAdd(acc + 2 * (i0 / B) + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x < 2) atomicAdd(acc + 2 * (i0 / B) + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
   } else if (lane == 0 && idx < 3 * B) {
-    unsafeAtomicAdd(acc + 2 * (idx / B), joint);
-    unsafeAtomicAdd(acc + 2 * (idx / B) + 1, marg);
+    atomicAdd(acc + 2 * (idx / B), joint);
+    atomicAdd(acc + 2 * (idx / B) + 1, marg);
+  }
+  // The block that finishes last turns the sums into the estimates:
+  // mi[m] = mean(joint scores) - log(mean(exp(shuffled scores)) + 1e-8)      (graph_fusion.py:497-499)
+  // (acc[6] counts finished blocks; the sums are read with atomics, i.e. from L2, where every block's adds have landed)
+  __shared__ int last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(reinterpret_cast<unsigned*>(acc + 6), 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (last && threadIdx.x < 3) {
+    const int m = threadIdx.x;
+    const float sj = atomicAdd(acc + 2 * m, 0.f), sm = atomicAdd(acc + 2 * m + 1, 0.f);
+    mi[m] = sj / (float)B - __logf(sm / (float)B + 1e-8f);
   }
 }
-// mi[m] = mean(joint scores) - log(mean(exp(shuffled scores)) + 1e-8)      (graph_fusion.py:497-499)
-__global__ void mi_finish_kernel(const float* __restrict__ acc, float* __restrict__ mi, int B) {
-  const int m = threadIdx.x;
-  if (m < 3) mi[m] = acc[2 * m] / (float)B - __logf(acc[2 * m + 1] / (float)B + 1e-8f);
+
+// Uniform random row permutations (torch.randperm's role, graph_fusion.py:494): block p sorts B (random key, index)
+// pairs in LDS with a bitonic network and writes the indices.  Keys are the counter-based hash of (seed + epoch, p, i);
+// equal keys are ordered by index, so the result is a function of the seed alone.
+constexpr int kPermMax = 4096;
+__global__ __launch_bounds__(1024) void perm_kernel(long long* __restrict__ out, int B, int n2, uint64_t seed, const uint64_t* __restrict__ epoch) {
+  __shared__ unsigned long long key[kPermMax];
+  if (epoch != nullptr) seed += epoch[0] * 0xD1B54A32D192ED03ull;
+  const uint64_t sd = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(blockIdx.x + 1);
+  for (int i = threadIdx.x; i < n2; i += blockDim.x)
+    key[i] = i < B ? ((unsigned long long)ocean_hash32_lo(sd, (uint32_t)i) << 32) | (unsigned)i : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < n2 / 2; t += blockDim.x) {
+        const int i = 2 * t - (t & (j - 1)), l = i + j;         // the pair (i, i ^ j) with bit j of i clear
+        const bool up = (i & k) == 0;
+        const unsigned long long a = key[i], b = key[l];
+        if ((a > b) == up) { key[i] = b; key[l] = a; }
+      }
+      __syncthreads();
+    }
+  for (int i = threadIdx.x; i < B; i += blockDim.x) out[(size_t)blockIdx.x * B + i] = (long long)(key[i] & 0xFFFFFFFFull);
+}
+
+// total = wp * pred + wc * (0 + c[0] + c[1] + ...), in the reference's order of operations and without contraction into
+// fused multiply-adds (ocean_model.py:257-266); out = [total, pred, sum of c]
+__global__ void loss_combine_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ c, int n_c, float wp, float wc, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  float sc = 0.f;
+  for (int q = 0; q < n_c; ++q) sc = __fadd_rn(sc, c[q]);
+  out[0] = __fadd_rn(__fmul_rn(wp, pred[0]), __fmul_rn(wc, sc));
+  out[1] = pred[0];
+  out[2] = sc;
+}
+// d pred = wp * d total;  d c[q] = wc * d total + d csum     (either upstream gradient may be absent)
+__global__ void loss_combine_bwd_kernel(const float* __restrict__ d_total, const float* __restrict__ d_csum, int n_c, float wp, float wc,
+                                        float* __restrict__ d_pred, float* __restrict__ d_c) {
+  const int q = threadIdx.x;
+  const float dt = d_total ? d_total[0] : 0.f, ds = d_csum ? d_csum[0] : 0.f;
+  if (q == 0) d_pred[0] = wp * dt;
+  if (q < n_c) d_c[q] = __fadd_rn(__fmul_rn(wc, dt), ds);
 }
 }  // namespace
+
+int ocean_draw_permutations(int n_perm, int B, uint64_t seed, const uint64_t* seed_epoch, long long* out, void* stream) {
+  if (!out) return OCEAN_ERR_NULL;
+  if (n_perm <= 0 || B <= 0) return OCEAN_ERR_BAD_SHAPE;
+  if (B > kPermMax) return OCEAN_ERR_UNSUPPORTED;
+  int n2 = 2;
+  while (n2 < B) n2 <<= 1;
+  hipLaunchKernelGGL(perm_kernel, dim3(n_perm), dim3(n2 / 2 < 1024 ? (n2 / 2 < 64 ? 64 : n2 / 2) : 1024), 0, (hipStream_t)stream, out, B, n2, seed, seed_epoch);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int ocean_loss_combine_fwd(const float* pred, const float* c, int n_c, float wp, float wc, float* out3, void* stream) {
+  if (!pred || !out3 || (n_c > 0 && !c)) return OCEAN_ERR_NULL;
+  if (n_c < 0 || n_c > 64) return OCEAN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(loss_combine_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pred, c, n_c, wp, wc, out3);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int ocean_loss_combine_bwd(const float* d_total, const float* d_csum, int n_c, float wp, float wc, float* d_pred, float* d_c, void* stream) {
+  if (!d_pred || (n_c > 0 && !d_c)) return OCEAN_ERR_NULL;
+  if (n_c < 0 || n_c > 64) return OCEAN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_total, d_csum, n_c, wp, wc, d_pred, d_c);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
 
 size_t ocean_mi_workspace(const ocean_mi_shape* s) {
   return s && s->B > 0 && s->E > 0 ? al4((size_t)s->B * s->E) + al4((size_t)3 * s->B * s->E) + 8 : 0;
@@ -554,9 +634,7 @@ int ocean_mi_estimates(const ocean_mi_shape* s, const float* fused, const float*
     v[m].C = V + (size_t)m * B * E; v[m].ldc = E; v[m].M = B; v[m].N = E; v[m].K = E;
   }
   OCEAN_TRY(ocean_launch_gemm_batch(v, 3, st));
-  hipLaunchKernelGGL(mi_rows_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, U, V, perms, b0, w1, b1, acc, B, E);
-  OCEAN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(mi_finish_kernel, dim3(1), dim3(64), 0, st, acc, mi, B);
+  hipLaunchKernelGGL(mi_rows_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, U, V, perms, b0, w1, b1, acc, mi, B, E);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }

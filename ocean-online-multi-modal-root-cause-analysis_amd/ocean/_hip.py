@@ -138,6 +138,9 @@ def _declare_rest(lib) -> None:
     sig("ocean_conv_gemm_f32", c_int, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_int, vp)
     sig("ocean_linear_bwd_f32", c_int, vp, c_int, vp, c_int, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, vp)
     sig("ocean_mean_mid_f32", c_int, vp, vp, c_int, c_int, c_int, vp)
+    sig("ocean_draw_permutations", c_int, c_int, c_int, c_uint64, vp, vp, vp)
+    sig("ocean_loss_combine_fwd", c_int, vp, vp, c_int, c_float, c_float, vp, vp)
+    sig("ocean_loss_combine_bwd", c_int, vp, vp, c_int, c_float, c_float, vp, vp, vp)
     sig("ocean_mse_fwd", c_int, vp, vp, c_long, vp, vp)
     sig("ocean_mse_bwd", c_int, vp, vp, vp, c_long, vp, vp)
     sig("ocean_diversity_workspace", c_size_t, c_int, c_int)

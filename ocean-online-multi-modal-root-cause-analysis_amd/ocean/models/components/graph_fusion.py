@@ -101,9 +101,12 @@ class ContrastiveLearningModule(nn.Module):
                 B, P = stacked.shape[1], stacked.shape[2]
                 allz = self.gather_positives(stacked.permute(1, 0, 2).reshape(B, 3 * P))          # [B_all, 3P]
                 gathered, offset = allz.view(-1, 3, P).permute(1, 0, 2), self.rank_row_offset(B)
-            three = ops.infonce_pairs(stacked, self.infonce_loss.temperature, gathered, offset).unbind(0)   # one backward node
+            vec = ops.infonce_pairs(stacked, self.infonce_loss.temperature, gathered, offset)      # one backward node
+            three = vec.unbind(0)
             pairs = [(a, b) for i, a in enumerate(names) for b in names[i + 1:]]
-            return {f"{a}_{b}_contrastive": three[q] for q, (a, b) in enumerate(pairs)}
+            out = ops.StackedLosses({f"{a}_{b}_contrastive": three[q] for q, (a, b) in enumerate(pairs)})
+            out.stacked = vec          # the same values as one tensor, in the dictionary's order (OCEANModel.compute_loss)
+            return out
         gathered = {}
         if neg is None and self.gather_positives is not None and len(names) > 1:
             # data parallel: every modality but the first serves as the positive side of some pair; one collective
@@ -267,7 +270,15 @@ class GraphFusionModule(nn.Module):
     @staticmethod
     def draw_permutations(B: int, device) -> torch.Tensor:
         """Three independent uniform row permutations [3, B] (the reference draws torch.randperm(B) once per modality,
-        graph_fusion.py:489): the order of one row of uniform random keys each, in one draw and one sort."""
+        graph_fusion.py:494), from one launch: the sorted order of counter-based random keys, seeded from torch's CPU
+        generator (plus the device epoch counter, so that a replayed HIP graph draws new ones each time)."""
+        device = torch.device(device)
+        if device.type == "cuda" and B <= 4096:
+            out = torch.empty(3, B, device=device, dtype=torch.long)
+            with torch.cuda.device(device):
+                _hip.check(_hip.lib().ocean_draw_permutations(3, B, _hip.new_seed(1.0), _hip.seed_epoch(device).data_ptr(),
+                                                              out.data_ptr(), _hip.stream()), "ocean_draw_permutations")
+            return out
         return torch.rand(3, B, device=device).argsort(dim=1)
 
     def _mutual_information(self, fused, X, perms: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import logging
+import os
 from typing import Any, Dict, Optional
 
 import torch
@@ -95,9 +96,10 @@ class OCEANModel(nn.Module):
         self.prediction_loss_weight = config.training.prediction_loss_weight
         self.contrastive_loss_weight = config.training.contrastive_loss_weight
         # overlap_encoders: run the graph encoder on a second HIP stream next to the dilated CNN (same results).
-        # Off by default: measured on the 256-service / batch-1024 step it costs 0.5 ms (13.2 ms against 12.8) - the
-        # gather kernels take compute units and L2 from the matrix kernels for longer than they save.
-        self.overlap_encoders = False
+        # Off by default (OCEAN_OVERLAP_ENCODERS=1 turns it on for measurements): on the 256-service / batch-1024 step
+        # it costs 0.3 ms (10.77 ms against 10.50; 10.72 with the second stream at the lowest priority) - the gather
+        # kernels take compute units and L2 from the matrix kernels for longer than they save.
+        self.overlap_encoders = os.environ.get("OCEAN_OVERLAP_ENCODERS", "0") == "1"
         self._side_streams: Dict[torch.device, Any] = {}
 
     # ------------------------------------------------------------------ helpers
@@ -136,7 +138,8 @@ class OCEANModel(nn.Module):
     def _encoder_stream(self, dev: torch.device) -> "torch.cuda.Stream":
         st = self._side_streams.get(dev)
         if st is None:
-            st = self._side_streams[dev] = torch.cuda.Stream(dev)
+            st = torch.cuda.Stream(dev)
+            self._side_streams[dev] = st
         return st
 
     def _head_params(self):
@@ -191,12 +194,22 @@ class OCEANModel(nn.Module):
         return outputs
 
     def compute_loss(self, predictions: Dict[str, Any], targets: torch.Tensor, reduction: str = "mean") -> Dict[str, Any]:
-        losses: Dict[str, Any] = {}
+        losses: Dict[str, Any] = ops.LossDict()
         pred_loss = ops.binary_cross_entropy(predictions["root_cause_probs"], targets, reduction)
         losses["prediction_loss"] = pred_loss
-        total_c: Any = 0.0
-        for name, value in predictions.get("contrastive_losses", {}).items():
+        contrastive = predictions.get("contrastive_losses", {})
+        for name, value in contrastive.items():
             losses[f"contrastive_{name}"] = value
+        stacked = getattr(contrastive, "stacked", None)
+        if pred_loss.dim() == 0 and pred_loss.is_cuda and (stacked is not None or not contrastive):
+            # the scalar arithmetic below as one launch (and its backward as one)
+            total, csum, vec = ops.combine_losses(pred_loss, stacked, self.prediction_loss_weight, self.contrastive_loss_weight)
+            losses["contrastive_loss"] = csum if contrastive else 0.0
+            losses["total_loss"] = total
+            losses.vec = vec
+            return losses
+        total_c: Any = 0.0
+        for value in contrastive.values():
             total_c = total_c + value
         losses["contrastive_loss"] = total_c
         losses["total_loss"] = self.prediction_loss_weight * pred_loss + self.contrastive_loss_weight * total_c

@@ -160,18 +160,18 @@ class _GraphedStep:
         # now, outside the capture (the two eager steps before a recording left a gradient on every trained parameter)
         opt.reserve_table_host([p for g in opt.param_groups for p in g["params"] if p.grad is not None])
         opt.zero_grad(set_to_none=True)            # gradients are re-created inside the graph's memory pool
+        one = learner._one()
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.epoch.add_(1)
             outputs = model(self.metrics, service_graph, self.logs)
             losses = model.compute_loss(outputs, self.labels)
-            losses["total_loss"].backward()
+            losses["total_loss"].backward(gradient=one)
             if learner.grad_sync is not None:
                 learner.grad_sync(model)               # RCCL collectives: recorded as nodes of the graph
             opt.step(max_norm=clip if clip > 0 else 0.0)
-            self.keys = [k for k in ("total_loss", "prediction_loss", "contrastive_loss") if torch.is_tensor(losses.get(k))]
-            self.loss_vec = torch.stack([losses[k].detach().float().reshape(()) for k in self.keys])
+            self.keys, self.loss_vec = learner._loss_vector(losses)
             if learner.data_parallel is not None:
                 self.loss_vec = learner.data_parallel.reduce_losses(self.loss_vec)
         self.outputs = outputs
@@ -232,14 +232,14 @@ class OnlineLearner:
         self._prefetched = None
         self._graph_seen: Dict[Any, int] = defaultdict(int)
         self._replay_warned: set = set()
+        self._seed_one: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ the update step
     def _losses_to_host(self, losses: Dict[str, Any]) -> Dict[str, float]:
         """total / prediction / contrastive loss values with one device read."""
-        keys = [k for k in ("total_loss", "prediction_loss", "contrastive_loss") if torch.is_tensor(losses.get(k))]
+        keys, vec = self._loss_vector(losses)
         vals = []
         if keys:
-            vec = torch.stack([losses[k].detach().float().reshape(()) for k in keys])
             if self.data_parallel is not None:
                 vec = self.data_parallel.reduce_losses(vec)      # every rank reports (and schedules on) the global means
             vals = vec.cpu().tolist()
@@ -248,6 +248,25 @@ class OnlineLearner:
             if k in losses and k not in out:
                 out[k] = float(losses[k])
         return out
+
+    @staticmethod
+    def _loss_vector(losses: Dict[str, Any]):
+        """(names, device vector) of the total / prediction / contrastive losses that are tensors: compute_loss's own
+        [total, prediction, contrastive] vector when it left one, else the scalars stacked."""
+        keys = [k for k in ("total_loss", "prediction_loss", "contrastive_loss") if torch.is_tensor(losses.get(k))]
+        vec = getattr(losses, "vec", None)
+        if vec is not None and keys[:2] == ["total_loss", "prediction_loss"]:
+            return keys, vec.detach()[:len(keys)]
+        if not keys:
+            return keys, None
+        return keys, torch.stack([losses[k].detach().float().reshape(()) for k in keys])
+
+    def _one(self) -> torch.Tensor:
+        """The backward pass's seed gradient (autograd would otherwise fill a fresh tensor with 1 on every step)."""
+        dev = self.model.device
+        if self._seed_one is None or self._seed_one.device != dev:
+            self._seed_one = torch.ones((), device=dev, dtype=torch.float32)
+        return self._seed_one
 
     def _train_mode(self) -> None:
         """model.train() as the reference calls it before every update (online_learner.py:304,375), skipped when
@@ -270,7 +289,11 @@ class OnlineLearner:
 
     def _apply_update(self, total_loss: torch.Tensor) -> None:
         self.optimizer.zero_grad()
-        self._weighted(total_loss).backward()
+        loss = self._weighted(total_loss)
+        if loss.dim() == 0 and loss.dtype == torch.float32 and loss.device == self.model.device:
+            loss.backward(gradient=self._one())
+        else:
+            loss.backward()
         if self.grad_sync is not None:
             self.grad_sync(self.model)
         clip = self.config.training.gradient_clip_norm

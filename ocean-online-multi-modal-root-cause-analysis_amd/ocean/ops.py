@@ -147,6 +147,53 @@ def infonce_pairs(projections: torch.Tensor, temperature: float = 0.1, gathered:
     return _InfoNce3.apply(projections.contiguous().float(), gathered, float(temperature), int(label_offset))
 
 
+class StackedLosses(dict):
+    """A dictionary of scalar losses that may also carry them as ONE tensor, `stacked` [n] in the dictionary's order
+    (None when the entries are separate tensors): combine_losses then reads one operand and its backward writes one."""
+    stacked: Optional[torch.Tensor] = None
+
+
+class LossDict(dict):
+    """compute_loss's result; `vec` (or None) holds [total, prediction, contrastive] as one device tensor, so that the
+    learner's read-back needs no stacking launch."""
+    vec: Optional[torch.Tensor] = None
+
+
+class _CombineLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, stacked, wp, wc):
+        out = torch.empty(3, device=pred.device, dtype=torch.float32)
+        n = 0 if stacked is None else stacked.numel()
+        _hip.check(_hip.lib().ocean_loss_combine_fwd(_hip.dev_ptr(pred, "prediction loss"), _hip.dev_ptr(stacked, "contrastive losses"), n,
+                                                     wp, wc, _hip.dev_ptr(out), _hip.stream()), "ocean_loss_combine_fwd")
+        ctx.cfg = (wp, wc, n, None if stacked is None else stacked.shape)
+        ctx.set_materialize_grads(False)
+        total, csum = out[0], out[2]
+        ctx.mark_non_differentiable(out)
+        return total, csum, out
+
+    @staticmethod
+    def backward(ctx, d_total, d_csum, _d_out):
+        wp, wc, n, shape = ctx.cfg
+        ref = d_total if d_total is not None else d_csum
+        if ref is None:
+            return None, None, None, None
+        d_pred = torch.empty((), device=ref.device, dtype=torch.float32)
+        d_c = None if n == 0 else torch.empty(shape, device=ref.device, dtype=torch.float32)
+        f = lambda g: None if g is None else g.contiguous().float()
+        _hip.check(_hip.lib().ocean_loss_combine_bwd(_hip.dev_ptr(f(d_total)), _hip.dev_ptr(f(d_csum)), n, wp, wc, _hip.dev_ptr(d_pred),
+                                                     _hip.dev_ptr(d_c), _hip.stream()), "ocean_loss_combine_bwd")
+        return d_pred, d_c, None, None
+
+
+def combine_losses(pred: torch.Tensor, stacked: Optional[torch.Tensor], wp: float, wc: float):
+    """(total, contrastive sum, [total, pred, contrastive sum]) with total = wp * pred + wc * (0 + stacked[0] + ...),
+    the arithmetic of OCEANModel.compute_loss (ocean_model.py:257-266) in one launch (one more in backward)."""
+    if pred.dim() != 0 or pred.dtype != torch.float32 or (stacked is not None and (stacked.dim() != 1 or stacked.dtype != torch.float32)):
+        raise ValueError("combine_losses takes an fp32 scalar and an fp32 vector")
+    return _CombineLosses.apply(pred, None if stacked is None else stacked.contiguous(), float(wp), float(wc))
+
+
 class _Bce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, probs, targets, mean_n):

@@ -308,3 +308,64 @@ def test_memory_bank_mode_replays_as_a_hip_graph(B):
         close(bb, ba, 1e-3)
     for a, b in zip(runs[False][1], runs[True][1]):
         close(b, a, 3e-3)
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 37, 64, 1000, 1024, 4096])
+def test_device_permutations(B):
+    """ocean_draw_permutations (torch.randperm's role in the mutual-information estimate, graph_fusion.py:494): every row
+    is a permutation of 0..B-1, rows are independent draws, the draw follows the seed and the device epoch counter."""
+    import ocean
+    from ocean import _hip
+    from ocean.models.components import GraphFusionModule
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    a = GraphFusionModule.draw_permutations(B, dev)
+    assert a.shape == (3, B) and a.dtype == torch.long
+    want = torch.arange(B, device=dev)
+    for m in range(3):
+        assert torch.equal(a[m].sort().values, want)
+    torch.manual_seed(5)
+    assert torch.equal(GraphFusionModule.draw_permutations(B, dev), a)          # same seed, same draw
+    if B >= 37:
+        assert not torch.equal(a[0], a[1]) and not torch.equal(a[1], a[2])
+        assert not torch.equal(GraphFusionModule.draw_permutations(B, dev), a)  # the generator moved on
+        torch.manual_seed(5)
+        _hip.seed_epoch(dev).add_(1)
+        assert not torch.equal(GraphFusionModule.draw_permutations(B, dev), a)  # a replay's epoch bump redraws
+        _hip.seed_epoch(dev).sub_(1)
+    if B == 4096:
+        # roughly uniform: element 0 lands in each quarter of the positions about equally often over many draws
+        pos = torch.stack([(GraphFusionModule.draw_permutations(B, dev) == 0).nonzero()[:, 1] for _ in range(200)]).flatten()
+        hist = torch.histc(pos.float(), bins=4, min=0, max=B)
+        assert hist.min() > 100 and hist.max() < 200, hist
+        out = torch.empty(3, B + 1, device=dev, dtype=torch.long)
+        st = _hip.lib().ocean_draw_permutations(3, B + 1, 1, None, out.data_ptr(), _hip.stream())
+        assert st != 0                                                          # larger draws are the caller's
+
+
+def test_fused_loss_arithmetic_matches_the_separate_operations():
+    """compute_loss's one-launch total (ocean_loss_combine_fwd / _bwd) against the reference's chain of scalar
+    operations (ocean_model.py:257-266): bit-equal values, equal gradients, and the read-back vector."""
+    from ocean import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    for wp, wc in [(1.0, 0.1), (0.7, 0.3), (1.0, 0.0)]:
+        pred = torch.rand((), generator=g).to(dev).requires_grad_()
+        c = torch.rand(3, generator=g).to(dev).requires_grad_()
+        total, csum, vec = ops.combine_losses(pred, c, wp, wc)
+        pr, cr = pred.detach().clone().requires_grad_(), c.detach().clone().requires_grad_()
+        tc = 0.0
+        for q in range(3):
+            tc = tc + cr[q]
+        tr = wp * pr + wc * tc
+        assert torch.equal(total.detach(), tr.detach()) and torch.equal(csum.detach(), tc.detach())
+        assert torch.equal(vec, torch.stack([tr.detach(), pr.detach(), tc.detach()]))
+        (2.0 * total + 0.5 * csum).backward()
+        (2.0 * tr + 0.5 * tc).backward()
+        assert torch.allclose(pred.grad, pr.grad, rtol=1e-6, atol=0) and torch.allclose(c.grad, cr.grad, rtol=1e-6, atol=0)
+    # no contrastive terms (evaluation): total = wp * pred
+    pred = torch.tensor(0.37, device=dev, requires_grad=True)
+    total, csum, vec = ops.combine_losses(pred, None, 0.9, 0.1)
+    assert torch.equal(total.detach(), (0.9 * pred).detach()) and float(csum.detach()) == 0.0
+    total.backward()
+    assert abs(float(pred.grad) - 0.9) < 1e-7

@@ -200,7 +200,7 @@ def test_large_kernels_with_padded_leading_dimensions():
 
 
 @pytest.mark.parametrize("M,N,K", [(3072, 256, 256), (1024, 768, 256), (1024, 128, 256), (1024, 12, 64), (1000, 100, 36), (333, 64, 512),
-                                   (96, 32, 32), (8192, 64, 64), (20000, 64, 64), (1024, 7, 64), (64, 768, 768)])
+                                   (96, 32, 32), (8192, 64, 64), (20000, 64, 64), (1024, 7, 64), (64, 768, 768), (8, 64, 128), (1, 128, 64), (5, 32, 36)])
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_linear_layer_gradient_pair(M, N, K, accumulate):
     """dW += dy^T x, db += column sums of dy and dx (+)= dy W of one layer: shapes whose two products share one
