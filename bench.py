@@ -283,9 +283,9 @@ def main():
                        "parallelism": f"dp{world}" + (" (rehearsal: all ranks on one GPU, gloo)" if rehearse else ""),
                        "launch": "hip-graph replay" + (" (collectives inside the graph)" if use_dist else "") if graphed else "eager"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": recorded_traffic(dom["kernel"]),
-                         "traffic_unit": "bytes/launch (HBM-side fetch+write, separate rocprofv3 --pmc passes of this command; "
-                                         "null unless recorded with this very library and script)",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": recorded_traffic(dom["kernel"]) if (B, T, N, world, use_dist) == (1024, 128, 256, 1, False) else None,
+                         "traffic_unit": "bytes/launch (HBM-side fetch+write, separate rocprofv3 --pmc passes of the default command; "
+                                         "null unless recorded with this very library and script, and for any other shape)",
                          "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "kernel": dom["kernel"],
                          "launches_per_step": dom["launches"] / prof_steps,
                          "avg_launch_ms": dom["total_ms"] / dom["launches"],

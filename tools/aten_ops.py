@@ -40,12 +40,13 @@ class Sites(TorchDispatchMode):
         name = str(func)
         if any(k in name for k in ("fill", "zero", "copy", "sort", "cat", "stack", "arange", "ones", "add", "mul", "rand", "full", "empty_like", "clone")):
             frames = [f for f in traceback.extract_stack() if "/ocean/" in f.filename or f.filename.endswith("bench.py")]
-            key = (name, f"{os.path.relpath(frames[-1].filename, ROOT)}:{frames[-1].lineno}" if frames else "?")
+            key = (name, " <- ".join(f"{os.path.relpath(f.filename, ROOT).split('_amd/')[-1]}:{f.lineno}" for f in frames[-1:-3:-1]) if frames else "?")
             sites[key] = sites.get(key, 0) + 1
         return func(*args, **(kwargs or {}))
 
 
-with Sites():
+# backward on this thread, so that the mode (thread-local) sees the operators autograd and the Functions' backward call
+with torch.autograd.set_multithreading_enabled(False), Sites():
     learner.process_tensors(metrics, graph, logs, labels)
 torch.cuda.synchronize()
 print("-- call sites")
