@@ -351,6 +351,24 @@ int ocean_loss_combine_fwd(const float* pred, const float* c, int n_c, float wp,
 int ocean_loss_combine_bwd(const float* d_total, const float* d_csum, int n_c, float wp, float wc, float* d_pred,
                            float* d_c, void* stream);
 
+/* The prediction loss and compute_loss's arithmetic together (ocean_model.py:249-266): pred = BCE(probs, targets)
+ * summed and divided by mean_n (0 -> n), then out3 as ocean_loss_combine_fwd writes it; one launch each way instead
+ * of three and two.  The per-block sums are added in block order by the block that finishes last, so the value does
+ * not vary from run to run.  `state` is zero-initialised device memory that the caller keeps for these calls (one per
+ * device; calls that overlap on one GPU must not share it).  Backward: d_probs = (wp * d_total + d_pred) * dBCE,
+ * d_c[q] = wc * d_total + d_csum (a NULL upstream gradient counts as zero). */
+#define OCEAN_LOSS_STATE_BLOCKS 512
+typedef struct {
+  float partial[OCEAN_LOSS_STATE_BLOCKS];   /* per-block sums of the call under way */
+  unsigned done;                            /* blocks that have finished; zero between calls */
+  unsigned pad_[3];
+} ocean_loss_state;
+int ocean_pred_total_fwd(const float* probs, const float* targets, long n, long mean_n, const float* c, int n_c,
+                         float wp, float wc, ocean_loss_state* state, float* out3, void* stream);
+int ocean_pred_total_bwd(const float* probs, const float* targets, const float* d_total, const float* d_csum,
+                         const float* d_pred, long n, long mean_n, int n_c, float wp, float wc, float* d_probs,
+                         float* d_c, void* stream);
+
 /* F.binary_cross_entropy(probs, targets, reduction='mean') (ocean_model.py:249-253; trainer.py:79).
  * *loss is ACCUMULATED; mean over mean_n elements (0 -> n). */
 int ocean_bce_fwd(const float* probs, const float* targets, long n, long mean_n, float* loss, void* stream);
@@ -394,6 +412,20 @@ int ocean_clip_adam_step(const ocean_adam_chunk* table, int n_chunks, const doub
 int ocean_clip_adam_step_dev(const ocean_adam_chunk* table, int n_chunks, const double* sqnorm, float max_norm,
                              const float* lr_dev, const int* step_dev, float beta1, float beta2, float eps,
                              float weight_decay, int write_clipped, void* stream);
+/* The whole clip + Adam step (online_learner.py:325-335: clip_grad_norm_ then optimizer.step) as two launches that need
+   no preparation between steps: the squared norm is accumulated into state->sq_acc (zero on entry), the update runs
+   for step *step_dev + 1, and the block of the update kernel that finishes last publishes the squared norm in
+   state->sq_last, puts sq_acc back to zero and stores the advanced count in *step_dev.  `state` is 24 zero-initialised
+   bytes of device memory that belong to this optimizer.  max_norm <= 0: no clipping, no norm launch. */
+typedef struct {
+  double sq_acc;      /* sum of squared gradients of the step under way; zero between steps */
+  double sq_last;     /* the finished step's sum (its square root is clip_grad_norm_'s return value) */
+  unsigned done;      /* blocks of the update kernel that have finished; zero between steps */
+  unsigned pad_;
+} ocean_adam_tail;
+int ocean_clip_adam_step_auto(const ocean_adam_chunk* table, int n_chunks, ocean_adam_tail* state, float max_norm,
+                              const float* lr_dev, int* step_dev, float beta1, float beta2, float eps,
+                              float weight_decay, int write_clipped, void* stream);
 
 /* ------------------------------------------------------------------ kernel timing (measurement aid)
  * No counterpart in the reference.  While enabled, every GEMM launch is bracketed by HIP events on its

@@ -582,7 +582,79 @@ __global__ void loss_combine_bwd_kernel(const float* __restrict__ d_total, const
   if (q == 0) d_pred[0] = wp * dt;
   if (q < n_c) d_c[q] = __fadd_rn(__fmul_rn(wc, dt), ds);
 }
+
+// The prediction loss and compute_loss's arithmetic in one launch: every block leaves the sum of its elements' BCE terms
+// in state->partial[block]; the block that signs off last adds the partial sums in block order (the same value on every
+// run, where atomic adds would vary in the last bits), forms the mean and then [total, pred, sum of c] as
+// loss_combine_fwd_kernel does, and puts the counter back to zero for the next call.
+__global__ __launch_bounds__(256) void pred_total_fwd_kernel(const float* __restrict__ p, const float* __restrict__ y, long n, float inv_n,
+                                                             const float* __restrict__ c, int n_c, float wp, float wc,
+                                                             ocean_loss_state* __restrict__ state, float* __restrict__ out) {
+  __shared__ float red[kWaves];
+  __shared__ bool last;
+  float s = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float lp = fmaxf(logf(p[i]), -100.f), lq = fmaxf(log1pf(-p[i]), -100.f);
+    s -= y[i] * lp + (1.0f - y[i]) * lq;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&state->partial[blockIdx.x], red[0] + red[1] + red[2] + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = atomicAdd(&state->done, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = 0.f;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) t += __hip_atomic_load(&state->partial[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const float pred = (red[0] + red[1] + red[2] + red[3]) * inv_n;
+  float sc = 0.f;
+  for (int q = 0; q < n_c; ++q) sc = __fadd_rn(sc, c[q]);
+  out[0] = __fadd_rn(__fmul_rn(wp, pred), __fmul_rn(wc, sc));
+  out[1] = pred;
+  out[2] = sc;
+  state->done = 0u;
+}
+// dp = (wp * d total + d pred) * (p - y) / max(p (1-p), 1e-12) / n;   d c[q] = wc * d total + d csum   (block 0)
+__global__ void pred_total_bwd_kernel(const float* __restrict__ p, const float* __restrict__ y, const float* __restrict__ d_total,
+                                      const float* __restrict__ d_csum, const float* __restrict__ d_pred, long n, float inv_n, int n_c,
+                                      float wp, float wc, float* __restrict__ dp, float* __restrict__ d_c) {
+  const float dt = d_total ? d_total[0] : 0.f;
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_c) d_c[threadIdx.x] = __fadd_rn(__fmul_rn(wc, dt), d_csum ? d_csum[0] : 0.f);
+  const float g = (wp * dt + (d_pred ? d_pred[0] : 0.f)) * inv_n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dp[i] = g * (p[i] - y[i]) / fmaxf(p[i] * (1.0f - p[i]), 1e-12f);
+}
 }  // namespace
+
+int ocean_pred_total_fwd(const float* probs, const float* targets, long n, long mean_n, const float* c, int n_c, float wp, float wc,
+                         ocean_loss_state* state, float* out3, void* stream) {
+  if (!probs || !targets || !state || !out3 || (n_c > 0 && !c)) return OCEAN_ERR_NULL;
+  if (n <= 0 || n_c < 0 || n_c > 64) return OCEAN_ERR_BAD_SHAPE;
+  const int blocks = egrid(n) > OCEAN_LOSS_STATE_BLOCKS ? OCEAN_LOSS_STATE_BLOCKS : egrid(n);
+  hipLaunchKernelGGL(pred_total_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, probs, targets, n,
+                     1.0f / (float)(mean_n > 0 ? mean_n : n), c, n_c, wp, wc, state, out3);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int ocean_pred_total_bwd(const float* probs, const float* targets, const float* d_total, const float* d_csum, const float* d_pred, long n,
+                         long mean_n, int n_c, float wp, float wc, float* dprobs, float* d_c, void* stream) {
+  if (!probs || !targets || !dprobs || (n_c > 0 && !d_c)) return OCEAN_ERR_NULL;
+  if (n <= 0 || n_c < 0 || n_c > 64) return OCEAN_ERR_BAD_SHAPE;
+  hipLaunchKernelGGL(pred_total_bwd_kernel, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, probs, targets, d_total, d_csum, d_pred, n,
+                     1.0f / (float)(mean_n > 0 ? mean_n : n), n_c, wp, wc, dprobs, d_c);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
 
 int ocean_draw_permutations(int n_perm, int B, uint64_t seed, const uint64_t* seed_epoch, long long* out, void* stream) {
   if (!out) return OCEAN_ERR_NULL;

@@ -34,10 +34,13 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const ocean_adam_chunk* __r
 __global__ __launch_bounds__(256) void clip_adam_kernel(const ocean_adam_chunk* __restrict__ tab, const double* __restrict__ sqnorm,
                                                         float max_norm, float lr, float b1, float b2, float eps, float wd,
                                                         float bc1, float bc2, int write_clipped,
-                                                        const float* __restrict__ lr_dev, const int* __restrict__ step_dev) {
+                                                        const float* __restrict__ lr_dev, const int* __restrict__ step_dev,
+                                                        ocean_adam_tail* __restrict__ tail) {
+  int t_now = 0;
   if (lr_dev != nullptr) {     // learning rate and step count live on the device (HIP-graph replays)
     lr = lr_dev[0];
-    const float t = (float)step_dev[0];
+    t_now = step_dev[0] + (tail != nullptr ? 1 : 0);      // with a tail the count is advanced here, not by the caller
+    const float t = (float)t_now;
     bc1 = 1.0f - powf(b1, t);
     bc2 = 1.0f - powf(b2, t);
   }
@@ -47,7 +50,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ocean_adam_chunk* 
   float* m = reinterpret_cast<float*>(c.exp_avg);
   float* v = reinterpret_cast<float*>(c.exp_avg_sq);
   float coef = 1.f;
-  if (max_norm > 0.f && sqnorm) coef = fminf(1.f, max_norm / ((float)sqrt(sqnorm[0]) + 1e-6f));
+  const double sq_now = sqnorm ? sqnorm[0] : 0.0;
+  if (max_norm > 0.f && sqnorm) coef = fminf(1.f, max_norm / ((float)sqrt(sq_now) + 1e-6f));
   const float step = lr / bc1, rs2 = 1.0f / sqrtf(bc2);
   for (long i = threadIdx.x; i < c.n; i += 256) {
     const float gc = g[i] * coef;
@@ -58,6 +62,22 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ocean_adam_chunk* 
     const float vi = b2 * v[i] + (1.f - b2) * gd * gd;
     m[i] = mi; v[i] = vi;
     p[i] = pv - step * mi / (sqrtf(vi) * rs2 + eps);
+  }
+  if (tail == nullptr) return;
+  // The block that finishes last leaves the state the next step starts from: the squared norm published, its
+  // accumulator back at zero, the step count advanced.  Every block has read the accumulator and the count before it
+  // signs off, and the last one writes only after all have signed off.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned done = atomicAdd(&tail->done, 1u);
+    if (done == gridDim.x - 1) {
+      __threadfence();
+      tail->done = 0u;
+      tail->sq_last = sq_now;
+      tail->sq_acc = 0.0;
+      const_cast<int*>(step_dev)[0] = t_now;
+    }
   }
 }
 
@@ -79,7 +99,7 @@ int ocean_clip_adam_step(const ocean_adam_chunk* table, int n_chunks, const doub
   if (n_chunks <= 0 || step < 1) return OCEAN_ERR_BAD_SHAPE;
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, sqnorm, max_norm, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2, write_clipped, (const float*)nullptr, (const int*)nullptr);
+                     weight_decay, bc1, bc2, write_clipped, (const float*)nullptr, (const int*)nullptr, (ocean_adam_tail*)nullptr);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }
@@ -90,7 +110,22 @@ int ocean_clip_adam_step_dev(const ocean_adam_chunk* table, int n_chunks, const 
   if (!table || !lr_dev || !step_dev) return OCEAN_ERR_NULL;
   if (n_chunks <= 0) return OCEAN_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(clip_adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, sqnorm, max_norm, 0.f, beta1, beta2, eps,
-                     weight_decay, 1.f, 1.f, write_clipped, lr_dev, step_dev);
+                     weight_decay, 1.f, 1.f, write_clipped, lr_dev, step_dev, (ocean_adam_tail*)nullptr);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int ocean_clip_adam_step_auto(const ocean_adam_chunk* table, int n_chunks, ocean_adam_tail* state, float max_norm, const float* lr_dev,
+                              int* step_dev, float beta1, float beta2, float eps, float weight_decay, int write_clipped,
+                              void* stream) {
+  if (!table || !lr_dev || !step_dev || !state) return OCEAN_ERR_NULL;
+  if (n_chunks <= 0) return OCEAN_ERR_BAD_SHAPE;
+  if (max_norm > 0.f) {
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, &state->sq_acc);
+    OCEAN_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, (const double*)&state->sq_acc, max_norm, 0.f,
+                     beta1, beta2, eps, weight_decay, 1.f, 1.f, write_clipped, lr_dev, (const int*)step_dev, state);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }

@@ -141,6 +141,8 @@ def _declare_rest(lib) -> None:
     sig("ocean_draw_permutations", c_int, c_int, c_int, c_uint64, vp, vp, vp)
     sig("ocean_loss_combine_fwd", c_int, vp, vp, c_int, c_float, c_float, vp, vp)
     sig("ocean_loss_combine_bwd", c_int, vp, vp, c_int, c_float, c_float, vp, vp, vp)
+    sig("ocean_pred_total_fwd", c_int, vp, vp, c_long, c_long, vp, c_int, c_float, c_float, vp, vp, vp)
+    sig("ocean_pred_total_bwd", c_int, vp, vp, vp, vp, vp, c_long, c_long, c_int, c_float, c_float, vp, vp, vp)
     sig("ocean_mse_fwd", c_int, vp, vp, c_long, vp, vp)
     sig("ocean_mse_bwd", c_int, vp, vp, vp, c_long, vp, vp)
     sig("ocean_diversity_workspace", c_size_t, c_int, c_int)
@@ -162,6 +164,7 @@ def _declare_rest(lib) -> None:
     sig("ocean_grad_sqnorm", c_int, vp, c_int, vp, vp)
     sig("ocean_clip_adam_step", c_int, vp, c_int, vp, c_float, c_float, c_float, c_float, c_float, c_float, c_int, c_int, vp)
     sig("ocean_clip_adam_step_dev", c_int, vp, c_int, vp, c_float, vp, vp, c_float, c_float, c_float, c_float, c_int, vp)
+    sig("ocean_clip_adam_step_auto", c_int, vp, c_int, vp, c_float, vp, vp, c_float, c_float, c_float, c_float, c_int, vp)
 
 
 def _declare_gnn(lib) -> None:
@@ -246,9 +249,14 @@ class GradArena:
     slots (zero_grads_like below) instead of into a fresh allocation per backward pass, so that after backward every
     p.grad is a view of the arena: a data-parallel caller all-reduces the arena in place (no packing into a bucket and
     back), and the optimizer's chunk table, which holds gradient addresses, never changes.  Assumes each component
-    runs once per backward pass (a second use would zero the first one's gradients instead of adding to them)."""
+    runs once per backward pass (a second use would zero the first one's gradients instead of adding to them).
 
-    def __init__(self, params):
+    step_scoped: the arena serves gradient buffers only between begin_step() and end_step() (an update step of a learner,
+    which calls both); any other backward pass through the same parameters gets fresh allocations, so callers that
+    accumulate gradients over several backward passes are not affected.  begin_step() zeroes the whole arena with one
+    fill, and the components' requests inside the step then find their slots already zero."""
+
+    def __init__(self, params, step_scoped: bool = False):
         params = [p for p in params]
         if not params:
             raise OceanHipError("GradArena needs parameters")
@@ -261,6 +269,16 @@ class GradArena:
             self.slots[p.data_ptr()] = (off, p.numel(), tuple(p.shape))
             off += (p.numel() + 3) // 4 * 4
         self.flat = torch.zeros(off, device=self.device, dtype=torch.float32)
+        self.step_scoped = bool(step_scoped)
+        self._in_step = False
+
+    def begin_step(self) -> None:
+        """One fill for all gradients of the coming backward pass."""
+        self.flat.zero_()
+        self._in_step = True
+
+    def end_step(self) -> None:
+        self._in_step = False
 
     def offset_of(self, p: torch.Tensor) -> int:
         return self.slots[p.data_ptr()][0]
@@ -268,6 +286,8 @@ class GradArena:
     def take(self, params, skip=None):
         """Views of the slots of `params` after zeroing the span they cover (one fill), or None when a parameter is
         not in this arena."""
+        if self.step_scoped and not self._in_step:
+            return None
         lo, hi, found = None, 0, []
         for i, p in enumerate(params):
             if skip is not None and skip[i]:
@@ -281,7 +301,8 @@ class GradArena:
             hi = max(hi, slot[0] + slot[1])
         if lo is None:
             return [None] * len(params)
-        self.flat[lo:hi].zero_()
+        if not self._in_step:
+            self.flat[lo:hi].zero_()
         return [None if sl is None else self.flat[sl[0]: sl[0] + sl[1]].view(sl[2]) for sl in found]
 
 

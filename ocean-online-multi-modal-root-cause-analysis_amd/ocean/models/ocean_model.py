@@ -195,12 +195,24 @@ class OCEANModel(nn.Module):
 
     def compute_loss(self, predictions: Dict[str, Any], targets: torch.Tensor, reduction: str = "mean") -> Dict[str, Any]:
         losses: Dict[str, Any] = ops.LossDict()
-        pred_loss = ops.binary_cross_entropy(predictions["root_cause_probs"], targets, reduction)
-        losses["prediction_loss"] = pred_loss
+        probs = predictions["root_cause_probs"]
         contrastive = predictions.get("contrastive_losses", {})
+        stacked = getattr(contrastive, "stacked", None)
+        if reduction in ("mean", "sum") and probs.is_cuda and probs.shape == targets.shape and (stacked is not None or not contrastive):
+            # the prediction loss and the scalar arithmetic below as one launch (and their backward as one)
+            total, pred_loss, csum, vec = ops.prediction_and_total(probs, targets, reduction, stacked, self.prediction_loss_weight,
+                                                                   self.contrastive_loss_weight)
+            losses["prediction_loss"] = pred_loss
+            for name, value in contrastive.items():
+                losses[f"contrastive_{name}"] = value
+            losses["contrastive_loss"] = csum if contrastive else 0.0
+            losses["total_loss"] = total
+            losses.vec = vec
+            return losses
+        pred_loss = ops.binary_cross_entropy(probs, targets, reduction)
+        losses["prediction_loss"] = pred_loss
         for name, value in contrastive.items():
             losses[f"contrastive_{name}"] = value
-        stacked = getattr(contrastive, "stacked", None)
         if pred_loss.dim() == 0 and pred_loss.is_cuda and (stacked is not None or not contrastive):
             # the scalar arithmetic below as one launch (and its backward as one)
             total, csum, vec = ops.combine_losses(pred_loss, stacked, self.prediction_loss_weight, self.contrastive_loss_weight)

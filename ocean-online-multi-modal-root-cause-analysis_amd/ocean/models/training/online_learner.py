@@ -159,15 +159,23 @@ class _GraphedStep:
         # the chunk table of the recorded optimizer step is staged through page-locked memory: allocate that buffer
         # now, outside the capture (the two eager steps before a recording left a gradient on every trained parameter)
         opt.reserve_table_host([p for g in opt.param_groups for p in g["params"] if p.grad is not None])
-        opt.zero_grad(set_to_none=True)            # gradients are re-created inside the graph's memory pool
+        opt.zero_grad(set_to_none=True)            # gradients are re-created inside the graph's memory pool (or live in the arena)
+        opt.settle()
         one = learner._one()
+        arena = learner._grad_arena()
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.epoch.add_(1)
             outputs = model(self.metrics, service_graph, self.logs)
             losses = model.compute_loss(outputs, self.labels)
-            losses["total_loss"].backward(gradient=one)
+            if arena is not None:
+                arena.begin_step()                     # one fill node for every gradient of the step
+            try:
+                losses["total_loss"].backward(gradient=one)
+            finally:
+                if arena is not None:
+                    arena.end_step()
             if learner.grad_sync is not None:
                 learner.grad_sync(model)               # RCCL collectives: recorded as nodes of the graph
             opt.step(max_norm=clip if clip > 0 else 0.0)
@@ -233,8 +241,31 @@ class OnlineLearner:
         self._graph_seen: Dict[Any, int] = defaultdict(int)
         self._replay_warned: set = set()
         self._seed_one: Optional[torch.Tensor] = None
+        # grad_arena: the gradients of an update live in one persistent buffer (ocean._hip.GradArena) that is zeroed
+        # with one fill before backward, instead of one fresh zero-filled allocation per component; their addresses
+        # then never change, so the optimizer's chunk table is built once
+        self.grad_arena = True
+        self._arena: Optional[_hip.GradArena] = None
 
     # ------------------------------------------------------------------ the update step
+    def _grad_arena(self) -> Optional[_hip.GradArena]:
+        """The arena the coming backward pass writes its parameter gradients into: the data-parallel wiring's when there
+        is one, else this learner's own (made on first use, for the model's current parameter tensors), or None."""
+        dp_arena = getattr(self.data_parallel, "arena", None)
+        if dp_arena is not None:
+            return dp_arena
+        if not self.grad_arena or self.model.device.type != "cuda" or not isinstance(self.optimizer, FusedAdam):
+            return None
+        params = [p for p in self.model.parameters() if p.dtype == torch.float32]
+        a = self._arena
+        if a is None or a.device != self.model.device or len(a.slots) != len(params) or any(
+                p.data_ptr() not in a.slots for p in params[:4] + params[-4:]):
+            if a is not None:
+                _hip.unregister_grad_arena(a)
+            a = self._arena = _hip.GradArena(params, step_scoped=True)
+            _hip.register_grad_arena(a)
+        return a
+
     def _losses_to_host(self, losses: Dict[str, Any]) -> Dict[str, float]:
         """total / prediction / contrastive loss values with one device read."""
         keys, vec = self._loss_vector(losses)
@@ -290,10 +321,17 @@ class OnlineLearner:
     def _apply_update(self, total_loss: torch.Tensor) -> None:
         self.optimizer.zero_grad()
         loss = self._weighted(total_loss)
-        if loss.dim() == 0 and loss.dtype == torch.float32 and loss.device == self.model.device:
-            loss.backward(gradient=self._one())
-        else:
-            loss.backward()
+        arena = self._grad_arena()
+        if arena is not None:
+            arena.begin_step()
+        try:
+            if loss.dim() == 0 and loss.dtype == torch.float32 and loss.device == self.model.device:
+                loss.backward(gradient=self._one())
+            else:
+                loss.backward()
+        finally:
+            if arena is not None:
+                arena.end_step()
         if self.grad_sync is not None:
             self.grad_sync(self.model)
         clip = self.config.training.gradient_clip_norm
@@ -421,8 +459,6 @@ class OnlineLearner:
         if self.model.contrastive_negatives != "in_batch" and not getattr(
                 self.model.fusion_module.contrastive_module, "device_ring", False):
             return "memory-bank negatives with the ring pointer kept on the host"
-        if self.optimizer.common_step(self._trained_params()) is None:
-            return "the trained parameters have different Adam step counts (a component was frozen for a while)"
         return None
 
     def _graph_step(self, metrics, service_graph, logs, labels) -> Optional[Dict[str, float]]:
@@ -451,6 +487,14 @@ class OnlineLearner:
             self._drop_recordings()                # the optimizer state was reloaded: every recording is stale
             step = None
         if step is None:
+            # (checked only when a step is about to be counted or recorded: the key holds the trainable set's version,
+            # so step counts cannot drift apart under an existing recording without the key changing)
+            if self.optimizer.common_step(self._trained_params()) is None:
+                why = "the trained parameters have different Adam step counts (a component was frozen for a while)"
+                if why not in self._replay_warned:
+                    self._replay_warned.add(why)
+                    logger.warning("use_hip_graph is set but the update step runs as separate launches: %s", why)
+                return None
             self._graph_seen[key] = self._graph_seen.pop(key, 0) + 1      # re-inserted: most recently seen last
             while len(self._graph_seen) > 64:                  # bounded: the signature seen longest ago goes first
                 self._graph_seen.pop(next(iter(self._graph_seen)))

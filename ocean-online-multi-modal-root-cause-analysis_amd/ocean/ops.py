@@ -194,6 +194,66 @@ def combine_losses(pred: torch.Tensor, stacked: Optional[torch.Tensor], wp: floa
     return _CombineLosses.apply(pred, None if stacked is None else stacked.contiguous(), float(wp), float(wc))
 
 
+_loss_states = {}
+
+
+def _loss_state(device) -> torch.Tensor:
+    """The zero-initialised ocean_loss_state of `device` (per-block sums and the finished-block counter of
+    ocean_pred_total_fwd), made on first use and kept: the kernel leaves the counter at zero."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _loss_states.get(key)
+    if t is None:
+        t = _loss_states[key] = torch.zeros(512 + 4, device=device, dtype=torch.float32)
+    return t
+
+
+class _PredTotal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probs, targets, mean_n, stacked, wp, wc):
+        out = torch.empty(3, device=probs.device, dtype=torch.float32)
+        n_c = 0 if stacked is None else stacked.numel()
+        _hip.check(_hip.lib().ocean_pred_total_fwd(_hip.dev_ptr(probs, "probs"), _hip.dev_ptr(targets, "targets"), probs.numel(), mean_n,
+                                                   _hip.dev_ptr(stacked, "contrastive losses"), n_c, wp, wc,
+                                                   _hip.dev_ptr(_loss_state(probs.device)), _hip.dev_ptr(out), _hip.stream()),
+                   "ocean_pred_total_fwd")
+        ctx.cfg = (mean_n, wp, wc, n_c, None if stacked is None else stacked.shape)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(probs, targets)
+        total, pred, csum = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(out)
+        return total, pred, csum, out
+
+    @staticmethod
+    def backward(ctx, d_total, d_pred, d_csum, _d_out):
+        mean_n, wp, wc, n_c, shape = ctx.cfg
+        probs, targets = ctx.saved_tensors
+        if d_total is None and d_pred is None and d_csum is None:
+            return None, None, None, None, None, None
+        dp = torch.empty_like(probs)
+        d_c = None if n_c == 0 else torch.empty(shape, device=probs.device, dtype=torch.float32)
+        f = lambda g: None if g is None else g.contiguous().float()
+        _hip.check(_hip.lib().ocean_pred_total_bwd(_hip.dev_ptr(probs), _hip.dev_ptr(targets), _hip.dev_ptr(f(d_total)), _hip.dev_ptr(f(d_csum)),
+                                                   _hip.dev_ptr(f(d_pred)), probs.numel(), mean_n, n_c, wp, wc, _hip.dev_ptr(dp),
+                                                   _hip.dev_ptr(d_c), _hip.stream()), "ocean_pred_total_bwd")
+        return dp, None, None, d_c, None, None
+
+
+def prediction_and_total(probs: torch.Tensor, targets: torch.Tensor, reduction: str, stacked: Optional[torch.Tensor], wp: float,
+                         wc: float):
+    """(total, prediction loss, contrastive sum, [total, prediction, contrastive sum]): binary_cross_entropy(probs,
+    targets, reduction) followed by combine_losses, as OCEANModel.compute_loss applies them (ocean_model.py:249-266), in
+    one launch (one more in backward).  reduction 'mean' or 'sum'."""
+    if probs.shape != targets.shape:
+        raise ValueError(f"Using a target size ({tuple(targets.shape)}) that is different to the input size "
+                         f"({tuple(probs.shape)}) is deprecated. Please ensure they have the same size.")
+    if reduction not in ("mean", "sum"):
+        raise ValueError(f"{reduction} is not a valid value for reduction")
+    if stacked is not None and (stacked.dim() != 1 or stacked.dtype != torch.float32):
+        raise ValueError("prediction_and_total takes the contrastive losses as one fp32 vector")
+    return _PredTotal.apply(probs.contiguous().float(), targets.to(probs.device).contiguous().float(),
+                            0 if reduction == "mean" else 1, None if stacked is None else stacked.contiguous(), float(wp), float(wc))
+
+
 class _Bce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, probs, targets, mean_n):

@@ -32,7 +32,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._tables = {}                    # per parameter group: chunk table, its key, chunk ranges per step count
         self._table = None                   # the first group's table (what a recorded step keeps alive)
         self._n_chunks = 0
-        self._sq = None
+        self._sq = None                      # fp64[3] on the device: ocean_adam_tail (accumulator, last step's sum, block counter)
+        self._sq_clean = True                # the accumulator is zero (the self-resetting step leaves it so)
         self.last_grad_norm: Optional[torch.Tensor] = None      # device scalar, set when max_norm is given
         # HIP-graph support: learning rate and step count mirrored in device memory (see make_capturable)
         self._lr_dev: Optional[torch.Tensor] = None
@@ -137,6 +138,13 @@ class FusedAdam(torch.optim.Optimizer):
                 self._lr_dev.fill_(lr)
                 self._lr_host = lr
 
+    def settle(self) -> None:
+        """Before a step is recorded: put the norm accumulator into the state the self-resetting step expects, now, so
+        that the recording does not contain a fill for it."""
+        if self._sq is not None and not self._sq_clean:
+            self._sq.zero_()
+            self._sq_clean = True
+
     def reserve_table_host(self, params) -> None:
         """Page-lock a chunk-table buffer sized for `params` now, so that a step() recorded into a HIP graph right
         after finds it in the free list instead of calling the pinned allocator while the stream is capturing."""
@@ -198,16 +206,34 @@ class FusedAdam(torch.optim.Optimizer):
             return loss
         self._table, self._n_chunks, self._table_host = plans[0][1]["table"], plans[0][1]["n"], plans[0][1]["host"]
         sq_ptr = ctypes.c_void_p(0)
+        device = plans[0][2]
+        if self._sq is None or self._sq.device != device:
+            self._sq = torch.zeros(3, dtype=torch.float64, device=device)
+            self._sq_clean = True
+        # device-side learning rate and step count, one group, one step count: norm + update need nothing in between
+        # (no fill of the accumulator, no increment of the count - the update kernel's last block does both)
+        if (self._step_dev is not None and len(plans) == 1 and len(self.param_groups) == 1 and len(plans[0][1]["ranges"]) == 1):
+            group, slot, _ = plans[0]
+            b1, b2 = group["betas"]
+            if not self._sq_clean:
+                self._sq.zero_()
+                self._sq_clean = True
+            _hip.check(L.ocean_clip_adam_step_auto(ctypes.c_void_p(slot["table"].data_ptr()), slot["n"], ctypes.c_void_p(self._sq.data_ptr()),
+                                                   float(max_norm or 0.0), ctypes.c_void_p(self._lr_dev.data_ptr()),
+                                                   ctypes.c_void_p(self._step_dev.data_ptr()), float(b1), float(b2),
+                                                   float(group["eps"]), float(group["weight_decay"]), int(write_clipped),
+                                                   _hip.stream()), "ocean_clip_adam_step_auto")
+            if max_norm and max_norm > 0:
+                self.last_grad_norm = self._sq[1:2]
+            return loss
         if max_norm and max_norm > 0:
-            device = plans[0][2]
-            if self._sq is None or self._sq.device != device:
-                self._sq = torch.zeros(1, dtype=torch.float64, device=device)
-            self._sq.zero_()
+            self._sq[0:1].zero_()
+            self._sq_clean = False
             sq_ptr = ctypes.c_void_p(self._sq.data_ptr())
             for _, slot, _ in plans:            # one sum of squares over every group, then every group clips by it
                 _hip.check(L.ocean_grad_sqnorm(ctypes.c_void_p(slot["table"].data_ptr()), slot["n"], sq_ptr, _hip.stream()),
                            "ocean_grad_sqnorm")
-            self.last_grad_norm = self._sq
+            self.last_grad_norm = self._sq[0:1]
         for group, slot, _ in plans:
             b1, b2 = group["betas"]
             tptr = slot["table"].data_ptr()
