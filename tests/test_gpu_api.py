@@ -226,6 +226,74 @@ def test_clip_norm_is_global_over_parameter_groups():
             close(q.grad, r.grad, 1e-5)
 
 
+def test_self_resetting_adam_step_matches_torch_adam():
+    """FusedAdam with the learning rate and the step count on the device (what a recorded step uses): the norm
+    accumulator is cleared and the count advanced by the update kernel itself (ocean_clip_adam_step_auto); five steps
+    with a changing learning rate against clip_grad_norm_ + torch.optim.Adam, with and without clipping."""
+    from ocean.optim import FusedAdam
+    for max_norm in (1.0, 0.0):
+        g = torch.Generator().manual_seed(9)
+        ps = [torch.randn(300, generator=g), torch.randn(17, 9, generator=g), torch.randn(70000, generator=g)]
+        gs = [torch.randn(p.shape, generator=g) for p in ps]
+        ref = [p.clone().requires_grad_(True) for p in ps]
+        got = [p.clone().cuda().requires_grad_(True) for p in ps]
+        ropt = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-4)
+        fopt = FusedAdam(got, lr=1e-2, weight_decay=1e-4)
+        for step in range(5):
+            for r, q, gr in zip(ref, got, gs):
+                r.grad = gr * (step + 1)
+                q.grad = (gr * (step + 1)).cuda()
+            if step == 1:
+                fopt.make_capturable(torch.device("cuda"))        # from here on: device-side lr / step, self-resetting kernels
+            if step == 3:
+                for o in (ropt, fopt):
+                    o.param_groups[0]["lr"] = 3e-3
+            norm = torch.nn.utils.clip_grad_norm_(ref, max_norm) if max_norm > 0 else None
+            ropt.step()
+            fopt.step(max_norm=max_norm)
+            if max_norm > 0:
+                assert abs(float(fopt.grad_norm()) - float(norm)) <= 1e-5 * float(norm)
+            for r, q in zip(ref, got):
+                close(q, r, 1e-5)
+        assert fopt._step_dev is not None and int(fopt._step_dev.item()) == 5
+        assert float(fopt._sq[0]) == 0.0 and int(fopt._sq[2:3].view(torch.int32)[0]) == 0     # left clean for the next step
+
+
+@pytest.mark.parametrize("n,n_c,reduction", [(7, 3, "mean"), (128 * 256, 3, "mean"), (1024 * 256 + 5, 3, "mean"), (300000, 0, "sum"), (4096, 1, "sum")])
+def test_prediction_and_total_matches_separate_calls(n, n_c, reduction):
+    """ocean_pred_total_fwd/_bwd (one launch each way) against binary_cross_entropy + combine_losses and against
+    torch's F.binary_cross_entropy, values and gradients, twice in a row (the finished-block counter must be back at
+    zero), including more elements than 512 blocks of 256 threads hold at one each."""
+    import torch.nn.functional as F
+    from ocean import ops
+    g = torch.Generator().manual_seed(n)
+    for rep in range(2):
+        logits = torch.randn(n, generator=g) * 3
+        y = (torch.rand(n, generator=g) < 0.1).float()
+        c = torch.rand(n_c, generator=g) if n_c else None
+        p_ref = torch.sigmoid(logits).requires_grad_(True)
+        c_ref = None if c is None else c.clone().requires_grad_(True)
+        pred_ref = F.binary_cross_entropy(p_ref, y, reduction=reduction)
+        csum_ref = 0.0
+        for q in range(n_c):
+            csum_ref = csum_ref + c_ref[q]
+        total_ref = 0.7 * pred_ref + 0.1 * csum_ref
+        (total_ref + 0.5 * pred_ref).backward()
+        p = torch.sigmoid(logits).cuda().requires_grad_(True)
+        cg = None if c is None else c.cuda().requires_grad_(True)
+        total, pred, csum, vec = ops.prediction_and_total(p.view(-1, 1), y.cuda().view(-1, 1), reduction, cg, 0.7, 0.1)
+        (total + 0.5 * pred).backward()
+        assert abs(float(pred) - float(pred_ref)) <= 2e-5 * abs(float(pred_ref))
+        assert abs(float(total) - float(total_ref)) <= 2e-5 * abs(float(total_ref))
+        assert vec.tolist() == [float(total), float(pred), float(csum)]
+        close(p.grad, p_ref.grad, 1e-5)
+        if n_c:
+            close(cg.grad, c_ref.grad, 1e-6)
+            # same block-ordered arithmetic on every run
+            total2 = ops.prediction_and_total(p.detach().view(-1, 1), y.cuda().view(-1, 1), reduction, cg.detach(), 0.7, 0.1)[0]
+            assert float(total2) == float(total)
+
+
 def test_replayed_steps_leave_a_frozen_components_step_count_alone():
     """After freeze_component, torch.optim.Adam no longer advances 'step' of the frozen parameters (they get no
     gradient); a recorded step must keep the same bookkeeping."""
