@@ -88,13 +88,16 @@ def test_large_graph_family_choice_by_size():
     assert m.edge_kernel_family(DeviceGraph.from_edge_index(sparse_in_degree_graph(4096, 8, 3), 4096, "cuda"), 64) == "node_per_wave"
 
 
-def test_large_graph_update_step_matches_oracle():
+@pytest.mark.parametrize("B,all_replicas", [(4, False), (64, True)])
+def test_large_graph_update_step_matches_oracle(B, all_replicas):
     """One whole in-batch update step with 4096 services: a 4096-wide prediction head and BCE, the graph given as a
-    sparse adjacency (no [4096, 4096] matrix on the product side)."""
+    sparse adjacency (no [4096, 4096] matrix on the product side).  B = 64 is one GPU's share of the configuration's
+    batch of 512 on eight GPUs, with every graph replica computed (as a step with dropout does): 262 144 node rows
+    through the kernels that read CSR from memory."""
     import ocean
     from ocean.data import ServiceGraph
     from ocean.optim import FusedAdam
-    N, B, T = 4096, 4, 128
+    N, T = 4096, 128
     cfg = ocean.default_config()
     cfg.model.num_services = N
     m = ocean.OCEANModel(cfg)
@@ -103,6 +106,8 @@ def test_large_graph_update_step_matches_oracle():
     m.load_state_dict(sd)
     m = m.cuda().train()
     m.contrastive_negatives = "in_batch"
+    if all_replicas:
+        m.spatial_encoder.dedupe_replicas = False
     gen = torch.Generator().manual_seed(5)
     ei = sparse_in_degree_graph(N, 8, 22)
     nf = torch.randn(N, 12, generator=gen)
@@ -116,6 +121,11 @@ def test_large_graph_update_step_matches_oracle():
     ro = R.model_forward(rsd, metrics, None, nf, logs, training=True, negatives="in_batch", edge_index=ei)
     rl = R.compute_loss(ro, labels)
     rl["total_loss"].backward()
+    if B > 8:
+        import torch.nn.functional as F
+        rsd64 = R.require_grad({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+        ro64 = R.model_forward(rsd64, metrics.double(), None, nf.double(), logs.double(), training=True, negatives="in_batch", edge_index=ei)
+        (F.binary_cross_entropy(ro64["root_cause_probs"], labels.double()) + 0.1 * sum(ro64["contrastive_losses"].values())).backward()
     # HIP path
     out = m(metrics, sg, logs)
     losses = m.compute_loss(out, labels.cuda())
@@ -132,6 +142,15 @@ def test_large_graph_update_step_matches_oracle():
             # get exact zeros (the reference's autograd does the same; the oracle leaves them out of its graph)
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
+        if B > 8 and k.startswith("temporal_encoder."):
+            # 8192 rows through seven ReLUs: a pre-activation within rounding of zero takes either sign depending on the
+            # summation order, and one such element moves a column sum of the BatchNorm backward by its full size.  Against
+            # the same oracle run in fp64 the fp32 CPU oracle itself is 6e-4 off (2-norm) on every tensor of this encoder
+            # and this path 2e-4 .. 2.7e-3 (tools/diag_c4_grad.py), so 1e-3 against the fp32 oracle is not a bound either
+            # side can keep here; the fp64 oracle is the yardstick, at 5e-3.
+            g, r = p.grad.detach().double().cpu(), rsd64[k].grad
+            assert (g - r).norm().item() <= 5e-3 * max(r.norm().item(), 1e-12), k
+            continue
         close(p.grad, rsd[k].grad, 1e-3, k)
     # the update itself: clip + Adam against the oracle's
     tk = [k for k in R.trainable_keys(rsd) if rsd[k].grad is not None]
@@ -142,8 +161,10 @@ def test_large_graph_update_step_matches_oracle():
     opt.step(max_norm=1.0)
     assert abs(float(opt.grad_norm()) - float(norm)) <= 1e-3 * float(norm)
     names = dict(m.named_parameters())
-    for k in ("prediction_head.6.weight", "spatial_encoder.conv_layers.0.lin.weight", "temporal_encoder.conv_layers.3.conv.weight"):
-        close(names[k], rsd[k], 5e-4, k)       # one Adam step moves an element by up to lr = 1e-3 whatever its gradient's size
+    # one Adam step moves an element by up to lr = 1e-3 whatever its gradient's size (so an element whose tiny gradient
+    # differs in sign ends 2e-3 apart: the temporal encoder's tensors are left out at the batch size where that happens)
+    for k in ("prediction_head.6.weight", "spatial_encoder.conv_layers.0.lin.weight") + (("temporal_encoder.conv_layers.3.conv.weight",) if B <= 8 else ()):
+        close(names[k], rsd[k], 5e-4, k)
 
 
 # ---------------------------------------------------------------- 64 concurrent streams
