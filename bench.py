@@ -144,10 +144,20 @@ def launch_ranks(n, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    worst = 0
-    for p in procs:
-        rc = p.wait()
-        worst = worst or rc
+    # wait for all of them; when one fails, the others (stuck in a collective that will never complete) are stopped
+    # instead of being waited for until the collective's own timeout
+    worst, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and worst == 0:
+                worst = rc
+                for other in live:
+                    other.terminate()
     return worst
 
 

@@ -224,3 +224,32 @@ def test_config_round_trip_and_defaults():
     with pytest.raises(ValueError):
         ServiceGraph(torch.eye(3), torch.randn(3, 2), service_names=["a"])
     assert ServiceGraph(torch.eye(3), torch.randn(3, 2)).to_edge_index().shape == (2, 3)
+
+
+def test_bench_rank_launcher_stops_the_other_ranks_when_one_fails(monkeypatch):
+    """bench.py --gpus N without a launcher starts N rank processes; when one of them exits with an error the others
+    would sit in a collective until its timeout: the launcher ends them and reports the failing rank's exit code."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    real = subprocess.Popen
+    seen = []
+
+    def stand_in(cmd, env=None):
+        rank = int(env["RANK"])
+        seen.append((rank, env["WORLD_SIZE"], env["MASTER_ADDR"]))
+        code = "import sys; sys.exit(3)" if rank == 1 else "import time; time.sleep(60)"
+        return real([sys.executable, "-c", code])
+
+    monkeypatch.setattr(subprocess, "Popen", stand_in)
+    t0 = time.time()
+    assert bench.launch_ranks(3, []) == 3
+    assert time.time() - t0 < 20
+    assert sorted(seen) == [(0, "3", "127.0.0.1"), (1, "3", "127.0.0.1"), (2, "3", "127.0.0.1")]
