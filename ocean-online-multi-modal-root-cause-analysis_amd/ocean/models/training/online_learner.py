@@ -256,12 +256,15 @@ class OnlineLearner:
             return dp_arena
         if not self.grad_arena or self.model.device.type != "cuda" or not isinstance(self.optimizer, FusedAdam):
             return None
-        params = [p for p in self.model.parameters() if p.dtype == torch.float32]
         a = self._arena
-        if a is None or a.device != self.model.device or len(a.slots) != len(params) or any(
-                p.data_ptr() not in a.slots for p in params[:4] + params[-4:]):
+        # two parameters from either end of the model stand for all of them: a move to another device or a reload that
+        # replaces tensors changes both (walking all 201 parameters on every step costs more host time than the fills the
+        # arena saves).  A component whose tensors are not in the arena simply gets fresh buffers (GradArena.take).
+        first, last = self.model.temporal_encoder.input_projection.weight, self.model.prediction_head[0].weight
+        if a is None or a.device != last.device or first.data_ptr() not in a.slots or last.data_ptr() not in a.slots:
             if a is not None:
                 _hip.unregister_grad_arena(a)
+            params = [p for p in self.model.parameters() if p.dtype == torch.float32]
             a = self._arena = _hip.GradArena(params, step_scoped=True)
             _hip.register_grad_arena(a)
         return a

@@ -189,18 +189,21 @@ class FusedAdam(torch.optim.Optimizer):
                 continue
             device = next(iter(by_step.values()))[0][0].device
             all_entries = [e for k in sorted(by_step) for e in by_step[k]]
+            # the table holds addresses only: it is rebuilt when a tensor moved or the parameters fall into other
+            # step-count groups, not because the counts themselves advanced (they do on every step)
             key = tuple((e[0].data_ptr(), e[1].data_ptr(), e[2].data_ptr()) for e in all_entries) + tuple(
-                (k, len(v)) for k, v in sorted(by_step.items()))
+                len(v) for _, v in sorted(by_step.items()))
             slot = self._tables.get(gi)
             if slot is None or slot["key"] != key:
                 table, n_chunks = self._build_table(all_entries, device)
-                # chunk ranges per distinct step count (normally one)
-                ranges, pos = [], 0
-                for k in sorted(by_step):
-                    n = sum((e[0].numel() + _CHUNK - 1) // _CHUNK for e in by_step[k])
-                    ranges.append((pos, n, k))
-                    pos += n
-                slot = self._tables[gi] = {"key": key, "table": table, "n": n_chunks, "ranges": ranges, "host": self._table_host}
+                # chunk counts per distinct step count (normally one)
+                counts = [sum((e[0].numel() + _CHUNK - 1) // _CHUNK for e in by_step[k]) for k in sorted(by_step)]
+                slot = self._tables[gi] = {"key": key, "table": table, "n": n_chunks, "counts": counts, "host": self._table_host}
+            ranges, pos = [], 0
+            for k, n in zip(sorted(by_step), slot["counts"]):
+                ranges.append((pos, n, k))
+                pos += n
+            slot["ranges"] = ranges
             plans.append((group, slot, device))
         if not plans:
             return loss
