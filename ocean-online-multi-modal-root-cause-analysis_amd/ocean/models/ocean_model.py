@@ -63,6 +63,32 @@ class _HeadFunction(torch.autograd.Function):
         return (dx, None, None) + tuple(g if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(grads))
 
 
+class _GraphedForward:
+    """One eval-mode forward pass (no gradients, no dropout, BatchNorm on its running statistics) recorded as a HIP graph
+    for fixed input shapes and a fixed service graph, and replayed with one launch.  The recorded kernels read the
+    parameters and buffers where they live, so updates made by training between two predictions are seen; the inputs are
+    copied into the recording's own tensors before a replay and the outputs are copied out after it.  The reference has
+    no counterpart (ocean_model.py:272-332 launches every operator from Python)."""
+
+    def __init__(self, model: "OCEANModel", metrics, service_graph, logs):
+        dev = model.device
+        self.metrics = metrics.detach().to(dev, torch.float32).clone()
+        self.logs = None if logs is None else logs.detach().to(dev, torch.float32).clone()
+        self.service_graph = service_graph
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.outputs = model._forward_impl(self.metrics, service_graph, self.logs, False)
+
+    def replay(self, metrics, logs) -> Dict[str, Any]:
+        self.metrics.copy_(metrics, non_blocking=True)
+        if self.logs is not None:
+            self.logs.copy_(logs, non_blocking=True)
+        self.graph.replay()
+        probs = self.outputs["root_cause_probs"].clone()
+        return {"root_cause_logits": self.outputs["root_cause_logits"].clone(), "root_cause_probs": probs, "prediction": probs}
+
+
 class OCEANModel(nn.Module):
     def __init__(self, config: OCEANConfig):
         super().__init__()
@@ -101,6 +127,12 @@ class OCEANModel(nn.Module):
         # kernels take compute units and L2 from the matrix kernels for longer than they save.
         self.overlap_encoders = os.environ.get("OCEAN_OVERLAP_ENCODERS", "0") == "1"
         self._side_streams: Dict[torch.device, Any] = {}
+        # use_hip_graph: an eval-mode forward under torch.no_grad() (predict_root_cause, get-style calls) is recorded as a
+        # HIP graph after two eager calls with the same input shapes and service graph, and replayed from then on
+        self.use_hip_graph = False
+        self.max_graphs = 4
+        self._graphed_fwd: Dict[Any, _GraphedForward] = {}
+        self._graph_fwd_seen: Dict[Any, int] = {}
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -149,6 +181,51 @@ class OCEANModel(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, metrics: torch.Tensor, service_graph: ServiceGraph, logs: Optional[torch.Tensor],
                 return_intermediate: bool = False) -> Dict[str, Any]:
+        if (self.use_hip_graph and not self.training and not torch.is_grad_enabled() and not return_intermediate
+                and not self.overlap_encoders and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing()):
+            out = self._replayed_forward(metrics, service_graph, logs)
+            if out is not None:
+                return out
+        return self._forward_impl(metrics, service_graph, logs, return_intermediate)
+
+    def _replayed_forward(self, metrics, service_graph, logs) -> Optional[Dict[str, Any]]:
+        """Replay (or, on the third call with one signature, record) the HIP graph of this eval-mode forward; None
+        while the signature is still new (the call then runs as ordinary launches)."""
+        mods = self.__dict__.get("_all_modules")
+        if mods is None:
+            mods = self.__dict__["_all_modules"] = list(self.modules())
+        if any(m.training for m in mods):
+            return None                       # a submodule left in training mode: dropout / batch statistics would be live
+        adj, nf = service_graph.adjacency_matrix, service_graph.node_features
+        sentinel = self.prediction_head[0].weight
+        key = (tuple(metrics.shape), None if logs is None else tuple(logs.shape), id(service_graph)) + DeviceGraph.tensor_key(adj) + (
+               nf.data_ptr(), nf._version, tuple(nf.shape), sentinel.data_ptr(), str(sentinel.device))
+        rec = self._graphed_fwd.get(key)
+        if rec is None:
+            n = self._graph_fwd_seen.pop(key, 0) + 1
+            self._graph_fwd_seen[key] = n
+            while len(self._graph_fwd_seen) > 64:
+                self._graph_fwd_seen.pop(next(iter(self._graph_fwd_seen)))
+            if n <= 2:
+                return None
+            before = torch.cuda.current_stream(self.device)
+            try:
+                rec = _GraphedForward(self, metrics, service_graph, logs)
+            except Exception as e:
+                torch.cuda.set_stream(before)
+                _hip.clear_last_error()
+                self.use_hip_graph = False
+                raise RuntimeError("recording the forward pass as a HIP graph failed; use_hip_graph has been switched off for "
+                                   "this model, but the process should be restarted before going on") from e
+            while len(self._graphed_fwd) >= max(1, self.max_graphs):
+                self._graphed_fwd.pop(next(iter(self._graphed_fwd)))
+        else:
+            self._graphed_fwd.pop(key)
+        self._graphed_fwd[key] = rec          # most recently used last
+        return rec.replay(metrics, logs)
+
+    def _forward_impl(self, metrics: torch.Tensor, service_graph: ServiceGraph, logs: Optional[torch.Tensor],
+                      return_intermediate: bool = False) -> Dict[str, Any]:
         dev = self.device
         if dev.type != "cuda":
             raise _hip.OceanHipError("OCEANModel runs on an MI355X: move it with .cuda(); there is no CPU path")

@@ -197,3 +197,60 @@ def test_freezing_a_component_is_not_replayed_over():
     for k, v in m.temporal_encoder.named_parameters():
         assert torch.equal(v, frozen[k]), k
     assert not torch.equal(m.prediction_head[0].weight, head)
+
+
+def test_replayed_eval_forward_equals_the_eager_one_and_sees_updated_weights():
+    """OCEANModel.use_hip_graph: predict_root_cause / an eval-mode forward under no_grad is recorded on its third call
+    with one signature and replayed afterwards.  Replays on new inputs (device and host tensors) give the eager
+    outputs, a training step in between is seen (the recording reads the parameters in place), another batch size gets
+    its own recording, and a forward that needs gradients or intermediates is never replayed."""
+    m, learner = _learner(True, False)
+    sg = _graph()
+    ref_model, _ = _learner(True, False)
+    ref_model.load_state_dict(m.state_dict())
+    m.use_hip_graph = True
+    m.eval(); ref_model.eval()
+
+    def check(i, B=4, host=False):
+        metrics, logs, _ = _data(i, B=B)
+        if host:
+            metrics, logs = metrics.cpu(), logs.cpu()
+        got = m.predict_root_cause(metrics, sg, logs, top_k=3)
+        ref = ref_model.predict_root_cause(metrics, sg, logs, top_k=3)
+        assert torch.equal(got["probabilities"], ref["probabilities"]), i          # same kernels, same order: bit-equal
+        assert torch.equal(got["top_k_indices"], ref["top_k_indices"])
+        return got
+
+    for i in range(6):
+        check(i, host=(i == 4))
+    assert len(m._graphed_fwd) == 1
+    held = check(6)["probabilities"]
+    snapshot = held.clone()
+    check(7)
+    assert torch.equal(held, snapshot)                    # a later replay does not overwrite what an earlier call returned
+    # a training step on both models, then predictions again
+    for mod, lr in ((m, learner), (ref_model, None)):
+        mod.train()
+    from ocean.models.training import OnlineLearner
+    ref_learner = OnlineLearner(ref_model, learner.config)
+    metrics, logs, labels = _data(50)
+    learner.process_tensors(metrics, sg, logs, labels)
+    ref_learner.process_tensors(metrics, sg, logs, labels)
+    m.eval(); ref_model.eval()
+    with torch.no_grad():
+        a = m(metrics, sg, logs)["root_cause_probs"]
+        b = ref_model(metrics, sg, logs)["root_cause_probs"]
+    assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item()      # the two training steps differ by atomics' order
+    assert len(m._graphed_fwd) == 1
+    for i in range(8, 12):
+        check(i, B=2)
+    assert len(m._graphed_fwd) == 2
+    # gradients wanted, or intermediates: ordinary launches
+    out = m(metrics, sg, logs, return_intermediate=True)
+    assert "intermediate" in out
+    out = m(metrics, sg, logs)
+    assert out["root_cause_probs"].requires_grad
+    m.train()
+    with torch.no_grad():
+        m(metrics, sg, logs)
+    assert len(m._graphed_fwd) == 2

@@ -1,11 +1,12 @@
 """Secondary measurements of the BASELINE configurations other than the headline one (one GPU, synthetic data):
 
   C1  README example (5 services, batch 1, seq_len 10, logs [1,10,768]): eval forward latency
+  P   predict_root_cause on 32 windows of the headline shape: serving latency
   C2  online step, 64 services, batch 256, seq_len 64, in-batch InfoNCE: samples/s
   C4  4096 services (CSR GAT, in-degree 8), batch 64 = one GPU's share of the 512 global batch: samples/s
   C5  per-window online updates (64 services, seq_len 64): update latency p50 / p99 for window batches of 8
 
-    python tools/bench_configs.py [C1 C2 C4 C5]
+    python tools/bench_configs.py [C1 P C2 C4 C5]
 
 Prints one JSON line per configuration.  Same synthetic-input recipe as bench.py.
 """
@@ -57,14 +58,26 @@ def timed(fn, warm, n):
     return ts
 
 
-def c1():
+def c1(use_graph=True):
     cfg, m, graph = make(5, 100, 0.0)
     m.eval()
+    m.use_hip_graph = use_graph
     metrics, logs = torch.randn(1, 10, 12, generator=g(1)).to(dev), torch.randn(1, 10, 768, generator=g(2)).to(dev)
     with torch.no_grad():
         ts = sorted(timed(lambda: m(metrics, graph, logs), 10, 200))
     return {"config": "C1 README eval forward (5 services, batch 1, seq_len 10)", "metric": "latency", "unit": "ms",
-            "p50": ts[len(ts) // 2] * 1e3, "p99": ts[int(len(ts) * 0.99)] * 1e3}
+            "p50": ts[len(ts) // 2] * 1e3, "p99": ts[int(len(ts) * 0.99)] * 1e3, "launch": "hip-graph replay" if m._graphed_fwd else "eager"}
+
+
+def predict(use_graph=True, B=32, N=256, T=128):
+    """predict_root_cause on a batch of windows of the headline shape (256 services, 128 timesteps): serving latency"""
+    cfg, m, graph = make(N, N, 8.0)
+    m.eval()
+    m.use_hip_graph = use_graph
+    metrics, logs, _ = inputs(B, T, N)
+    ts = sorted(timed(lambda: m.predict_root_cause(metrics, graph, logs, top_k=5), 10, 200))
+    return {"config": f"predict_root_cause ({N} services, batch {B}, seq_len {T}, top-5)", "metric": "latency", "unit": "ms",
+            "p50": ts[len(ts) // 2] * 1e3, "p99": ts[int(len(ts) * 0.99)] * 1e3, "launch": "hip-graph replay" if m._graphed_fwd else "eager"}
 
 
 def train_cfg(name, N, S, deg, B, T, steps, use_graph=True):
@@ -97,11 +110,13 @@ def c5(use_graph=True):
             "samples_per_s": 8 / (sum(ts) / len(ts)), "launch": "hip-graph replay" if learner._graphed else "eager"}
 
 
-which = sys.argv[1:] or ["C1", "C2", "C4", "C5"]
+which = sys.argv[1:] or ["C1", "P", "C2", "C4", "C5"]
 for w in which:
-    for use_graph in ((True,) if w == "C1" else (False, True)):
+    for use_graph in (False, True):
         if w == "C1":
-            r = c1()
+            r = c1(use_graph)
+        elif w == "P":
+            r = predict(use_graph)
         elif w == "C2":
             r = train_cfg("C2 online step (64 services, batch 256, seq_len 64, in-batch InfoNCE)", 64, 64, 4.0, 256, 64, 20, use_graph)
         elif w == "C4":
