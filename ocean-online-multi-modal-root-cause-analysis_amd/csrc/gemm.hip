@@ -648,7 +648,7 @@ bool ocean_gemm_bn_rides(const GemmP& p) {
     GemmBatch nb;
     nb.n = 1; nb.g[0] = p;
     if (nb.g[0].bn_u == nullptr) nb.g[0].bn_u = p.A;       // eligibility as it will be once the caller has set the bn_* fields
-    return ocean_gemm_nt_applies(nb);
+    return ocean_gemm_nt_applies(nb) || ocean_gemm_skinny_applies(nb);     // (the few-tile kernel has no full-tile condition)
   }
   GemmBatch b;
   b.n = 1; b.g[0] = p;

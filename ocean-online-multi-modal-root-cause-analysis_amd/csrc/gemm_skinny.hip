@@ -24,7 +24,15 @@ constexpr int kPairUnroll = 2;      // the same inside gemm_pair_kernel, whose 1
 // One 32x32 output tile by one group of 256 threads (tid = 0..255 inside the group; `part` is the group's own four
 // partial tiles).  Every thread of the block must call it, active or not: it holds a block-wide barrier.  An inactive
 // group (its tile index is past the problem's last tile) loads and stores nothing.
-template <bool BKN, int kUnroll>
+// CONV: the convolution-shaped launches of small batches as well - several taps (A's rows shifted per tap inside their
+// sample, B advancing by tap_stride_b; all taps are one reduction of taps * K, split over the four waves like any
+// other), the BatchNorm column statistics of the raw output, the BatchNorm-backward column sums of GemmP::bn_u and a
+// residual broadcast from one row per sample.  Only from gemm_skinny_kernel (one tile per block: the extra block-wide
+// barrier of the column sums needs every thread of the block in the same tile).
+// NW: waves that split the reduction of the tile (4; 8 for the long reductions of the convolution-shaped launches, where
+// one wave per SIMD with eight loads in flight left the tile waiting on L2 round trips); the epilogue is the first 256
+// threads' either way.
+template <bool BKN, int kUnroll, bool CONV = false, int NW = 4>
 __device__ __forceinline__ void skinny_tile(const GemmP& p, const int tile, const int tid, float (*part)[32][33]) {
   const int tiles_n = (p.N + 31) / 32, tiles_m = (p.M + 31) / 32;
   const bool active = tile < tiles_m * tiles_n;
@@ -34,8 +42,9 @@ __device__ __forceinline__ void skinny_tile(const GemmP& p, const int tile, cons
   const int lm = lane & 31, h = lane >> 5;
 
   // this wave's share of the reduction, in whole 8-deep steps
-  const int steps = (p.K + 7) / 8;
-  const int per = (steps + 3) / 4;
+  const int steps_tap = (p.K + 7) / 8;
+  const int steps = CONV ? steps_tap * p.taps : steps_tap;
+  const int per = (steps + NW - 1) / NW;
   const int s_begin = wave * per, s_end = active ? min(steps, s_begin + per) : s_begin;
 
   constexpr unsigned kOob = 0x80000000u;                         // out-of-range offset: a buffer load returns zeros
@@ -52,17 +61,29 @@ __device__ __forceinline__ void skinny_tile(const GemmP& p, const int tile, cons
     const unsigned x = r[0], y = r[1], z = r[2], w = r[3];
     v[0] = __uint_as_float(x); v[1] = __uint_as_float(y); v[2] = __uint_as_float(z); v[3] = __uint_as_float(w);
   };
+  const int t_row = (CONV && p.T > 0) ? (m0 + lm) % p.T : 0;      // this lane's row inside its sample
   auto load_step = [&](int s, float (&a)[4], float (&b)[4]) {
-    const int k = 8 * s + 4 * h;                                  // K % 4 == 0: a group of four is inside or outside
+    int tap = 0, ks = s;
+    if (CONV && p.taps > 1) { tap = s / steps_tap; ks = s - tap * steps_tap; }
+    const int k = 8 * ks + 4 * h;                                 // K % 4 == 0: a group of four is inside or outside
     const bool k_ok = s < s_end && k < p.K;
-    ld4(rsrc_a, (a_row_ok && k_ok) ? a_base + (unsigned)(8 * s) * 4u : kOob, a);
+    bool a_ok = a_row_ok && k_ok;
+    unsigned a_off = a_base + (unsigned)(8 * ks) * 4u, b_tap = 0u;
+    if (CONV) {
+      // (byte offsets are taken modulo 2^32: a negative shift wraps and comes back once the row part is added)
+      const int shift = p.shift0 + tap * p.shift_step;
+      if (p.T > 0) a_ok = a_ok && (unsigned)(t_row + shift) < (unsigned)p.T;
+      a_off += (unsigned)(shift * p.lda) * 4u;
+      b_tap = (unsigned)((long)tap * p.tap_stride_b) * 4u;
+    }
+    ld4(rsrc_a, a_ok ? a_off : kOob, a);
     if (BKN) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         b[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-            rsrc_b, (int)((b_col_ok && k_ok) ? b_base + (unsigned)(8 * s + t) * b_row : kOob), 0, 0));
+            rsrc_b, (int)((b_col_ok && k_ok) ? b_tap + b_base + (unsigned)(8 * ks + t) * b_row : kOob), 0, 0));
     } else {
-      ld4(rsrc_b, (b_col_ok && k_ok) ? b_base + (unsigned)(8 * s) * 4u : kOob, b);
+      ld4(rsrc_b, (b_col_ok && k_ok) ? b_tap + b_base + (unsigned)(8 * ks) * 4u : kOob, b);
     }
   };
 
@@ -103,12 +124,29 @@ __device__ __forceinline__ void skinny_tile(const GemmP& p, const int tile, cons
   const int col = n0 + (tid & 31);
   const bool col_ok = col < p.N;
   const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+  const bool bn_on = CONV && p.bn_u != nullptr, stats_on = CONV && p.colstats != nullptr;
+  DropoutP bn_drop = DropoutP{0.f, 0, nullptr};
+  float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
+  if (bn_on) {
+    bn_drop = dropout_resolve(p.bn_drop);
+    if (col_ok) { sc = p.bn_scale[col]; sh = p.bn_shift[col]; mu = p.bn_mean[col]; is = p.bn_invstd[col]; }
+  }
+  float cs_s = 0.f, cs_q = 0.f, bn_sg = 0.f, bn_sx = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int lr = (tid >> 5) + 8 * i, row = m0 + lr;
-    if (row >= p.M || !col_ok) continue;
-    float v = part[0][lr][tid & 31] + part[1][lr][tid & 31] + part[2][lr][tid & 31] + part[3][lr][tid & 31] + bias;
-    if (p.R != nullptr) v += p.R[(long)row * p.ldr + col];
+    if (row >= p.M || !col_ok || (NW > 4 && tid >= 256)) continue;
+    float raw = part[0][lr][tid & 31] + part[1][lr][tid & 31] + part[2][lr][tid & 31] + part[3][lr][tid & 31];
+    if (NW > 4) {
+#pragma unroll
+      for (int w = 4; w < NW; ++w) raw += part[w][lr][tid & 31];
+    }
+    if (stats_on) { cs_s += raw; cs_q += raw * raw; }
+    float v = raw + bias;
+    if (p.R != nullptr) {
+      if (CONV && p.r_bcast_T > 0) v += p.r_scale * p.R[(long)(row / p.r_bcast_T) * p.ldr + col];
+      else v += p.R[(long)row * p.ldr + col];
+    }
     if (p.relu) v = fmaxf(v, 0.f);
     if (drop.p > 0.f) {
       const uint64_t di = p.drop_group > 1 ? (uint64_t)(p.drop_row0 + row) * (p.N / p.drop_group) + col / p.drop_group
@@ -117,15 +155,52 @@ __device__ __forceinline__ void skinny_tile(const GemmP& p, const int tile, cons
     }
     if (p.relu_mask != nullptr && !(p.relu_mask[(long)row * p.ld_mask + col] > 0.f)) v = 0.f;
     p.C[(long)row * p.ldc + col] = v;
+    if (bn_on) {
+      const float u = p.bn_u[(long)row * p.ld_bn_u + col];
+      float g = (fmaf(u, sc, sh) > 0.f) ? v : 0.f;
+      if (bn_drop.p > 0.f) g *= dropout_keep(bn_drop, (uint64_t)row * p.N + col);
+      bn_sg += g;
+      bn_sx += g * (u - mu) * is;
+    }
+  }
+  if (CONV && (stats_on || bn_on)) {
+    // column sums over the tile's 32 rows: the eight row groups meet in shared memory (the partial tiles are spent)
+    __syncthreads();
+    float* red = &part[0][0][0];                  // [4][8][32]
+    const int rg = tid >> 5, cl = tid & 31;
+    if (NW == 4 || tid < 256) {
+      red[(0 * 8 + rg) * 32 + cl] = cs_s; red[(1 * 8 + rg) * 32 + cl] = cs_q;
+      red[(2 * 8 + rg) * 32 + cl] = bn_sg; red[(3 * 8 + rg) * 32 + cl] = bn_sx;
+    }
+    __syncthreads();
+    if (tid < 32 && col_ok) {
+      float t[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        t[q] = 0.f;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) t[q] += red[(q * 8 + g8) * 32 + tid];
+      }
+      if (stats_on) {
+        double* cs = p.colstats + (size_t)(tile_m % p.colstat_slots) * 2 * p.N;
+        unsafeAtomicAdd(cs + col, (double)t[0]);
+        unsafeAtomicAdd(cs + p.N + col, (double)t[1]);
+      }
+      if (bn_on) {
+        double* bs = p.bn_slots + (size_t)(tile_m % p.bn_nslots) * 2 * p.N;
+        unsafeAtomicAdd(bs + col, (double)t[2]);
+        unsafeAtomicAdd(bs + p.N + col, (double)t[3]);
+      }
+    }
   }
 }
 
-template <bool BKN>
-__global__ __launch_bounds__(kThreads) void gemm_skinny_kernel(const GemmBatch batch) {
+template <bool BKN, bool CONV = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(const GemmBatch batch) {
   const GemmP& p = batch.g[blockIdx.y];
   if ((int)blockIdx.x >= ((p.N + 31) / 32) * ((p.M + 31) / 32)) return;   // the grid is sized for the largest problem of the batch
-  __shared__ float part[4][32][33];
-  skinny_tile<BKN, kSkinnyUnroll>(p, blockIdx.x, threadIdx.x, part);
+  __shared__ float part[NW][32][33];
+  skinny_tile<BKN, kSkinnyUnroll, CONV, NW>(p, blockIdx.x, threadIdx.x, part);
 }
 
 // Row reductions with a small output (a linear layer's weight gradient C[M][N] += sum_k A[k][m] B[k][n] over a few
@@ -269,18 +344,27 @@ static bool skinny_rows_applies(const GemmBatch& b, const int min_rows = 64) {
   return tiles32 <= 128;
 }
 
+// a problem that needs the convolution-shaped variant of the tile (taps, column statistics, BatchNorm-backward sums, a
+// residual broadcast per sample)
+static bool skinny_conv(const GemmP& p) {
+  return p.taps != 1 || p.T > 0 || p.colstats != nullptr || p.bn_u != nullptr || p.r_bcast_T > 0;
+}
+
 bool ocean_gemm_skinny_applies(const GemmBatch& b) {
   static const bool off = getenv("OCEAN_GEMM_NO_SKINNY") != nullptr;       // measurement switch
   if (off) return false;
   if (b.g[0].a_kmajor) return skinny_rows_applies(b);
+  static const bool conv_off = getenv("OCEAN_GEMM_NO_SKINNY_CONV") != nullptr;   // measurement switch
   long blocks64 = 0, tiles32 = 0;
   for (int q = 0; q < b.n; ++q) {
     const GemmP& p = b.g[q];
-    if (p.a_kmajor || p.taps != 1 || p.colstats != nullptr || p.bn_u != nullptr || p.a_colsum != nullptr || p.r_bcast_T > 0) return false;
+    if (p.a_kmajor || p.a_colsum != nullptr) return false;
+    if (skinny_conv(p) && (conv_off || b.n != 1)) return false;
     if (p.b_kn != b.g[0].b_kn) return false;
     if (p.K % 4 != 0 || p.K < 32 || !al16(p.A) || p.lda % 4 != 0) return false;
-    if (!p.b_kn && (!al16(p.B) || p.ldb % 4 != 0)) return false;
-    if ((double)p.M * p.lda >= 5.0e8 || (double)(p.b_kn ? p.K : p.N) * p.ldb >= 5.0e8) return false;   // 32-bit byte offsets
+    if (!p.b_kn && (!al16(p.B) || p.ldb % 4 != 0 || p.tap_stride_b % 4 != 0)) return false;
+    // 32-bit byte offsets
+    if ((double)p.M * p.lda >= 5.0e8 || (double)(p.b_kn ? p.K : p.N) * p.ldb + (double)(p.taps - 1) * (double)p.tap_stride_b >= 5.0e8) return false;
     blocks64 += (long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
     tiles32 += (long)ceil_div(p.M, 32) * ceil_div(p.N, 32);
   }
@@ -363,6 +447,7 @@ int ocean_launch_gemm_pair(const GemmP* w, int nw, const GemmP* d, int nd, hipSt
     // a reduction of a few rows (small batches) is no work for sixteen waves, but here it rides in a launch that is made anyway
     static const bool skinny_off = getenv("OCEAN_GEMM_NO_SKINNY") != nullptr;
     pair = pair && !skinny_off && wb.g[0].K <= 8192 && skinny_rows_applies(wb, 1) && ocean_gemm_skinny_applies(db);
+    for (int q = 0; q < nd && pair; ++q) pair = !skinny_conv(d[q]);      // the pair kernel's data-gradient role is the plain tile
     for (int q = 0; q < nd && pair; ++q)
       for (int r = 0; r < nw && pair; ++r) {
         const GemmP &x = d[q], &y = w[r];
@@ -406,12 +491,25 @@ int ocean_launch_gemm_skinny(const GemmBatch& b, hipStream_t stream) {
     const GemmP& p = b.g[q];
     const int t = ceil_div(p.M, 32) * ceil_div(p.N, 32);
     if (t > tiles) tiles = t;
-    flops += 2.0 * p.M * p.N * (double)p.K;
-    bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N);
+    flops += 2.0 * p.M * p.N * (double)p.K * p.taps;
+    bytes += 4.0 * ((double)p.M * p.K + (double)p.N * p.K * p.taps + (double)p.M * p.N);
   }
   void* tok = nullptr;
-  if (ocean_prof_on()) ocean_prof_begin(b.g[0].b_kn ? "gemm_skinny_kernel<true>" : "gemm_skinny_kernel<false>", flops, bytes, stream, &tok);
-  if (b.g[0].b_kn) hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3(tiles, b.n), dim3(kThreads), 0, stream, b);
+  const bool conv = skinny_conv(b.g[0]);
+  if (ocean_prof_on()) ocean_prof_begin(conv ? (b.g[0].b_kn ? "gemm_skinny_kernel<true, true>" : "gemm_skinny_kernel<false, true>")
+                                             : (b.g[0].b_kn ? "gemm_skinny_kernel<true>" : "gemm_skinny_kernel<false>"), flops, bytes, stream, &tok);
+  if (conv) {
+    // reductions of 384 and more (48 eight-deep steps) are split over eight waves
+    const bool wide = (long)((b.g[0].K + 7) / 8) * b.g[0].taps >= 48;
+    if (b.g[0].b_kn) {
+      if (wide) hipLaunchKernelGGL((gemm_skinny_kernel<true, true, 8>), dim3(tiles, b.n), dim3(512), 0, stream, b);
+      else hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), dim3(tiles, b.n), dim3(kThreads), 0, stream, b);
+    } else {
+      if (wide) hipLaunchKernelGGL((gemm_skinny_kernel<false, true, 8>), dim3(tiles, b.n), dim3(512), 0, stream, b);
+      else hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), dim3(tiles, b.n), dim3(kThreads), 0, stream, b);
+    }
+  }
+  else if (b.g[0].b_kn) hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3(tiles, b.n), dim3(kThreads), 0, stream, b);
   else hipLaunchKernelGGL(gemm_skinny_kernel<false>, dim3(tiles, b.n), dim3(kThreads), 0, stream, b);
   ocean_prof_end(tok, stream);
   OCEAN_LAUNCH_CHECK();
