@@ -232,8 +232,9 @@ template <int CPL>
 __global__ __launch_bounds__(256) void gat_aggregate_fast_kernel(GatK g, int hlog, const float* __restrict__ Z,
                                                                  const float* __restrict__ a_s, const float* __restrict__ a_d,
                                                                  float* __restrict__ agg, float* __restrict__ smax,
-                                                                 float* __restrict__ sden) {
+                                                                 float* __restrict__ sden, GatEpi epi) {
   g.att_drop = dropout_resolve(g.att_drop);
+  epi.fd = dropout_resolve(epi.fd);
   __shared__ float wl_all[kWavesPerBlock][64];
   __shared__ int jl_all[kWavesPerBlock][64];
   __shared__ float dl_all[kWavesPerBlock][16];
@@ -248,6 +249,15 @@ __global__ __launch_bounds__(256) void gat_aggregate_fast_kernel(GatK g, int hlo
   const int hk = lane >> (6 - hlog), c0 = lane * CPL;  // channel-role coordinates
   const float adl = a_d[(rbase + i) * H + lh];
   const int e0 = g.rp_in[i], e1 = g.rp_in[i + 1];
+  // what the output stage at the end needs from memory is requested now, ahead of the gathers
+  const int Cw = g.HC >> hlog, od = epi.concat ? g.HC : Cw;
+  const int oc0 = epi.concat ? c0 : c0 - hk * Cw;          // this lane's first output channel
+  const bool writes_y = epi.y != nullptr && (epi.concat || hk == 0);
+  float bias_r[CPL], xin_r[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) { bias_r[k] = 0.f; xin_r[k] = 0.f; }
+  if (epi.y != nullptr) load_row<CPL>(epi.bias + oc0, bias_r);
+  if (writes_y && epi.xin != nullptr) load_row<CPL>(epi.xin + (epi.xin_rows > 0 ? (long)i : node) * od + oc0, xin_r);
   const bool single = (e1 - e0) <= EPW;
   float mx = -INFINITY, s_last = -INFINITY;
   int j_last = 0;
@@ -301,7 +311,24 @@ __global__ __launch_bounds__(256) void gat_aggregate_fast_kernel(GatK g, int hlo
   const float inv = 1.0f / (dl[hk] + 1e-16f);
 #pragma unroll
   for (int k = 0; k < CPL; ++k) acc[k] *= inv;
-  store_row<CPL>(agg + node * g.HC + c0, acc);
+  store_row<CPL>(agg + node * g.HC + c0, acc);     // kept: the backward pass takes the ReLU mask from it
+  if (epi.y != nullptr) {
+    // the layer's output stage on the row while it is in registers (what gat_epilogue_kernel does in a pass of its own):
+    // mean over the heads (or their concatenation), bias, ReLU, feature dropout, residual
+    float o[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      float v = acc[k];
+      if (!epi.concat) {
+        for (int sh = 64 >> hlog; sh < 64; sh <<= 1) v += __shfl_xor(v, sh);     // sum over the heads
+        v *= 1.0f / (float)H;
+      }
+      v = fmaxf(v + bias_r[k], 0.f);
+      if (epi.fd.p > 0.f && writes_y) v *= dropout_keep(epi.fd, (uint64_t)(node * od + oc0 + k));
+      o[k] = v + xin_r[k];
+    }
+    if (writes_y) store_row<CPL>(epi.y + node * od + oc0, o);
+  }
 }
 
 // da_d[row, h] = sum over the incoming edges e of row's node of ds_edge[(r*E + e), h]   (edges of one target are
@@ -1327,7 +1354,10 @@ int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features, const in
                         ws + pl.smax[l], ws + pl.sden[l], epi);
       if (fused) { xin = ws + pl.y[l]; continue; }
     } else if (fast_edges(pl)) {
-      GAT_DISPATCH_FAST(gat_aggregate_fast_kernel, ws + pl.Z[l], ws + pl.as_[l], ws + pl.ad[l], ws + pl.agg[l], ws + pl.smax[l], ws + pl.sden[l]);
+      const bool fused = getenv("OCEAN_GAT_NO_FUSED_EPI") == nullptr;       // measurement switch, read per call
+      const GatEpi epi{params[pg_layer(l, 3)], pl.residual[l] ? xin : nullptr, fused ? ws + pl.y[l] : nullptr, shared ? s->N : 0, pl.concat[l], feat_drop(s, l)};
+      GAT_DISPATCH_FAST(gat_aggregate_fast_kernel, ws + pl.Z[l], ws + pl.as_[l], ws + pl.ad[l], ws + pl.agg[l], ws + pl.smax[l], ws + pl.sden[l], epi);
+      if (fused) { xin = ws + pl.y[l]; continue; }
     } else {
       const int cpl = cpl_of(pl);
       const dim3 grid(ceil_div(rows, kWavesPerBlock)), block(256);
