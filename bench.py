@@ -205,7 +205,12 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:        # (single rank without a launcher) a free port, not a fixed one a run that just ended may still hold
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:

@@ -19,11 +19,11 @@ timeout -k 10 300 python -u $R/tools/bench_metrics.py 2>/dev/null > $OUT/metrics
 # (recorded with the collectives inside the graph, and eager), then the same at the full batch
 timeout -k 10 200 python $R/bench.py --batch 128 --no-cpu-baseline > $OUT/bench_b128.json 2> /tmp/bench_b128.err
 : > $OUT/bench_dp.jsonl
-OCEAN_BENCH_DIST=1 timeout -k 10 200 python $R/bench.py --batch 128 --no-cpu-baseline >> $OUT/bench_dp.jsonl 2> /tmp/bench_dp1.err
-OCEAN_BENCH_DIST=1 timeout -k 10 200 python $R/bench.py --batch 128 --no-cpu-baseline --no-graph >> $OUT/bench_dp.jsonl 2> /tmp/bench_dp2.err
-OCEAN_BENCH_DIST=1 timeout -k 10 200 python $R/bench.py --no-cpu-baseline >> $OUT/bench_dp.jsonl 2> /tmp/bench_dp3.err
+OCEAN_BENCH_DIST=1 timeout -k 10 200 python $R/bench.py --batch 128 --no-cpu-baseline >> $OUT/bench_dp.jsonl 2> $OUT/bench_dp1.err
+OCEAN_BENCH_DIST=1 timeout -k 10 200 python $R/bench.py --batch 128 --no-cpu-baseline --no-graph >> $OUT/bench_dp.jsonl 2> $OUT/bench_dp2.err
+OCEAN_BENCH_DIST=1 timeout -k 10 200 python $R/bench.py --no-cpu-baseline >> $OUT/bench_dp.jsonl 2> $OUT/bench_dp3.err
 # two ranks on this one GPU with host-staged gloo collectives: the N > 1 control flow only, its rate means nothing
-OCEAN_BENCH_REHEARSE=1 timeout -k 10 300 python $R/bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline >> $OUT/bench_dp.jsonl 2> /tmp/bench_dp4.err
+OCEAN_BENCH_REHEARSE=1 timeout -k 10 300 python $R/bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline >> $OUT/bench_dp.jsonl 2> $OUT/bench_dp4.err
 timeout -k 10 200 python -u $R/tools/bench_gemm_ksweep.py 2>/dev/null > $OUT/gemm_ksweep.txt
 bash $R/tools/prof_gnn.sh final/gat_instruction_mix.txt
 bash $R/tools/prof_gnn_traffic.sh final/gat_traffic.txt
