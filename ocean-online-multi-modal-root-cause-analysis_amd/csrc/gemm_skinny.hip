@@ -320,8 +320,9 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 }  // namespace
 
-// Whether the batch should take this kernel: plain products (one tap, no row reduction, no column statistics) whose
-// 64x64 tiling would occupy less than one block per compute unit, with operands the vector loads can address.
+// Whether the batch should take this kernel: products without a row reduction whose 64x64 tiling would occupy less than
+// one block per compute unit, with operands the vector loads can address - plain ones (one tap, no column statistics)
+// in batches of up to three, convolution-shaped ones (skinny_conv below) one at a time.
 // Row-reduction batches for gemm_skinny_rows_kernel: one tap, no row shifts, a reduction of at most 8192 rows (longer
 // ones fill the chip through the ring kernel's split, unless the output is a handful of tiles), at most 128 output tiles (with more, the 32x32 tiles' operand
 // re-reads from L2 cost more than the ring kernel's 64x64 tiles: 20-25 us measured at 384 tiles).
