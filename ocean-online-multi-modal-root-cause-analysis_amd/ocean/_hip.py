@@ -318,6 +318,32 @@ def unregister_grad_arena(arena: GradArena) -> None:
     _arenas[:] = [a for a in _arenas if a is not arena]
 
 
+def step_arena(owner) -> Optional[GradArena]:
+    """The arena an update step of `owner` (an OnlineLearner or a Trainer: .model, .optimizer, .data_parallel, .grad_arena,
+    ._arena) writes its parameter gradients into: the data-parallel wiring's when there is one, else the owner's own
+    step-scoped one (made on first use for the model's current parameter tensors), or None (switched off, not on a GPU,
+    not the fused optimizer)."""
+    dp_arena = getattr(getattr(owner, "data_parallel", None), "arena", None)
+    if dp_arena is not None:
+        return dp_arena
+    model = owner.model
+    from .optim import FusedAdam
+    last = model.prediction_head[0].weight
+    if not getattr(owner, "grad_arena", False) or last.device.type != "cuda" or not isinstance(owner.optimizer, FusedAdam):
+        return None
+    a = owner._arena
+    # two parameters from either end of the model stand for all of them: a move to another device or a reload that
+    # replaces tensors changes both (walking all 201 parameters on every step costs more host time than the fills the
+    # arena saves).  A component whose tensors are not in the arena simply gets fresh buffers (GradArena.take).
+    first = model.temporal_encoder.input_projection.weight
+    if a is None or a.device != last.device or first.data_ptr() not in a.slots or last.data_ptr() not in a.slots:
+        if a is not None:
+            unregister_grad_arena(a)
+        a = owner._arena = GradArena([p for p in model.parameters() if p.dtype == torch.float32], step_scoped=True)
+        register_grad_arena(a)
+    return a
+
+
 def zero_grads_like(params, skip=None):
     """Zero-initialised gradient buffers for `params` as views of ONE flat allocation (one fill kernel
     instead of one per tensor).  skip[i] True -> None for that slot.  With a registered GradArena that holds these

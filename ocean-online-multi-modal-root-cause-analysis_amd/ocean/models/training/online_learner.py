@@ -249,25 +249,8 @@ class OnlineLearner:
 
     # ------------------------------------------------------------------ the update step
     def _grad_arena(self) -> Optional[_hip.GradArena]:
-        """The arena the coming backward pass writes its parameter gradients into: the data-parallel wiring's when there
-        is one, else this learner's own (made on first use, for the model's current parameter tensors), or None."""
-        dp_arena = getattr(self.data_parallel, "arena", None)
-        if dp_arena is not None:
-            return dp_arena
-        if not self.grad_arena or self.model.device.type != "cuda" or not isinstance(self.optimizer, FusedAdam):
-            return None
-        a = self._arena
-        # two parameters from either end of the model stand for all of them: a move to another device or a reload that
-        # replaces tensors changes both (walking all 201 parameters on every step costs more host time than the fills the
-        # arena saves).  A component whose tensors are not in the arena simply gets fresh buffers (GradArena.take).
-        first, last = self.model.temporal_encoder.input_projection.weight, self.model.prediction_head[0].weight
-        if a is None or a.device != last.device or first.data_ptr() not in a.slots or last.data_ptr() not in a.slots:
-            if a is not None:
-                _hip.unregister_grad_arena(a)
-            params = [p for p in self.model.parameters() if p.dtype == torch.float32]
-            a = self._arena = _hip.GradArena(params, step_scoped=True)
-            _hip.register_grad_arena(a)
-        return a
+        """The arena the coming backward pass writes its parameter gradients into (ocean._hip.step_arena)."""
+        return _hip.step_arena(self)
 
     def _losses_to_host(self, losses: Dict[str, Any]) -> Dict[str, float]:
         """total / prediction / contrastive loss values with one device read."""

@@ -28,9 +28,10 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
-from ... import ops
+from ... import _hip, ops
 from ...configs import OCEANConfig
 from ...optim import FusedAdam
+from ..components import DeviceGraph
 from ..ocean_model import OCEANModel
 
 logger = logging.getLogger(__name__)
@@ -129,6 +130,70 @@ class LearningRateScheduler:
         return self.scheduler.get_last_lr()
 
 
+class _GraphedTrainStep:
+    """One Trainer.train_step (forward with intermediates, LossFunction, backward, gradient collectives, clip + Adam)
+    recorded as a HIP graph for fixed batch shapes and a fixed service graph, and replayed with one launch.  What changes
+    between steps lives in device memory: the inputs (copied in before a replay), the previous batch's temporal features
+    (the consistency term's second operand: a tensor of the recording that each replay reads and then overwrites with this
+    batch's), the dropout epoch, the optimizer's learning rate and step count.  The reference has no counterpart."""
+
+    def __init__(self, trainer: "Trainer", batch: Dict[str, Any]):
+        model, opt = trainer.model, trainer.optimizer
+        dev = trainer.device
+        params = [p for g in opt.param_groups for p in g["params"] if p.requires_grad and p.grad is not None]
+        if opt._step_dev is None:
+            opt.make_capturable(dev, params)
+        f32 = lambda t: t.detach().to(dev, torch.float32).clone()
+        self.metrics, self.logs, self.labels = f32(batch["metrics"]), f32(batch["logs"]), f32(batch["labels"])
+        self.service_graph = batch["graphs"][0]
+        self.prev = trainer.prev_temporal_features.detach().clone()
+        self.epoch = _hip.seed_epoch(dev)
+        self.generation = opt.generation
+        clip = trainer.config.training.gradient_clip_norm
+        opt.reserve_table_host([p for g in opt.param_groups for p in g["params"] if p.grad is not None])
+        opt.zero_grad(set_to_none=True)
+        opt.settle()
+        arena = _hip.step_arena(trainer)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.epoch.add_(1)
+            out = model(self.metrics, self.service_graph, self.logs, return_intermediate=True)
+            temporal = out["intermediate"]["temporal_features"]
+            losses = trainer.loss_function(out, self.labels, temporal, self.prev)
+            if arena is not None:
+                arena.begin_step()
+            try:
+                losses["total_loss"].backward()
+            finally:
+                if arena is not None:
+                    arena.end_step()
+            if trainer.grad_sync is not None:
+                trainer.grad_sync(model)
+            opt.step(max_norm=clip if clip > 0 else 0.0)
+            self.prev.copy_(temporal.detach())
+            self.keys = [k for k, v in losses.items() if torch.is_tensor(v)]
+            self.loss_vec = torch.stack([losses[k].detach().float().reshape(()) for k in self.keys])
+            self.consts = {k: float(v) for k, v in losses.items() if not torch.is_tensor(v)}
+        self.params = [p for g in opt.param_groups for p in g["params"] if p.grad is not None]
+        opt.bump_steps(self.params, -1)           # recording advanced the host-side step counters without running anything
+        self._keep = (opt._table_host, opt._table, opt._sq)
+
+    def replay(self, trainer: "Trainer", batch: Dict[str, Any]) -> Dict[str, float]:
+        self.metrics.copy_(batch["metrics"], non_blocking=True)
+        self.logs.copy_(batch["logs"], non_blocking=True)
+        self.labels.copy_(batch["labels"], non_blocking=True)
+        if trainer.prev_temporal_features is not self.prev:
+            self.prev.copy_(trainer.prev_temporal_features, non_blocking=True)
+        trainer.optimizer.sync_lr()
+        self.graph.replay()
+        trainer.optimizer.after_replay(self.params)
+        trainer.prev_temporal_features = self.prev
+        host = dict(zip(self.keys, self.loss_vec.cpu().tolist()))
+        host.update(self.consts)
+        return host
+
+
 class Trainer:
     def __init__(self, model: OCEANModel, config: OCEANConfig, data_loader: Any, optimizer: Optional[optim.Optimizer] = None,
                  device: Optional[torch.device] = None, use_wandb: bool = False):
@@ -152,6 +217,15 @@ class Trainer:
         self.prev_temporal_features: Optional[torch.Tensor] = None
         self.grad_sync = None                      # data-parallel hooks, see ocean.parallel.DataParallel
         self.data_parallel = None
+        # use_hip_graph: after two eager steps with the same batch shapes and service graph, train_step records the step
+        # as a HIP graph and replays it (fused optimizer, one parameter group; a batch of another shape - the ragged
+        # last one of an epoch - and the step after it run as ordinary launches).  grad_arena: as in OnlineLearner.
+        self.use_hip_graph = False
+        self.max_graphs = 2
+        self.grad_arena = True
+        self._arena = None
+        self._graphed: Dict[Any, _GraphedTrainStep] = {}
+        self._graph_seen: Dict[Any, int] = {}
 
     # ------------------------------------------------------------------ one batch
     def _move_batch_to_device(self, batch: Dict[str, Any]) -> Dict[str, Any]:
@@ -174,13 +248,75 @@ class Trainer:
         host.update({k: float(v) for k, v in losses.items() if not torch.is_tensor(v)})
         return host
 
+    def _graph_step(self, batch: Dict[str, Any]) -> Optional[Dict[str, float]]:
+        """Replay (or, on the third step with one signature, record) the HIP graph of this step; None when it has to run
+        as ordinary launches."""
+        opt = self.optimizer
+        if (self.device.type != "cuda" or not isinstance(opt, FusedAdam) or len(opt.param_groups) != 1
+                or (self.grad_sync is not None and not getattr(self.data_parallel, "capturable", False))
+                or not getattr(self.model.fusion_module.contrastive_module, "device_ring", True)
+                and self.model.contrastive_negatives != "in_batch"):
+            return None
+        metrics, logs, labels, sg = batch["metrics"], batch["logs"], batch["labels"], batch["graphs"][0]
+        prev = self.prev_temporal_features
+        if prev is None or prev.shape[0] != metrics.shape[0]:
+            return None                    # no consistency term on this step (first batch, or after a ragged one)
+        grp, adj, nf = opt.param_groups[0], sg.adjacency_matrix, sg.node_features
+        lf = self.loss_function
+        key = (tuple(metrics.shape), tuple(logs.shape), tuple(labels.shape), id(sg)) + DeviceGraph.tensor_key(adj) + (
+               nf.data_ptr(), nf._version, tuple(nf.shape), getattr(self.model, "trainable_version", 0), tuple(grp["betas"]), grp["eps"],
+               grp["weight_decay"], self.config.training.gradient_clip_norm, self.model.contrastive_negatives,
+               lf.prediction_weight, lf.contrastive_weight, lf.consistency_weight, lf.diversity_weight)
+        step = self._graphed.get(key)
+        if step is not None and step.generation != opt.generation:
+            self._graphed.clear()                  # the optimizer state was reloaded: every recording is stale
+            step = None
+        if step is None:
+            trained = [p for g in opt.param_groups for p in g["params"] if p.requires_grad and p.grad is not None]
+            if opt.common_step(trained) is None:
+                return None
+            n = self._graph_seen.pop(key, 0) + 1
+            self._graph_seen[key] = n
+            while len(self._graph_seen) > 64:
+                self._graph_seen.pop(next(iter(self._graph_seen)))
+            if n <= 2:
+                return None
+            before = torch.cuda.current_stream(self.device)
+            try:
+                step = _GraphedTrainStep(self, batch)
+            except Exception as e:
+                torch.cuda.set_stream(before)
+                _hip.clear_last_error()
+                self.use_hip_graph = False
+                opt.zero_grad(set_to_none=True)
+                raise RuntimeError("recording the training step as a HIP graph failed; use_hip_graph has been switched off for "
+                                   "this trainer, but the process should be restarted before training on") from e
+            while len(self._graphed) >= max(1, self.max_graphs):
+                old = self._graphed.pop(next(iter(self._graphed)))
+                opt.recycle_table_host(old._keep[0])
+        else:
+            self._graphed.pop(key)
+        self._graphed[key] = step
+        return step.replay(self, batch)
+
     def train_step(self, batch: Dict[str, Any]) -> Dict[str, float]:
         """Forward, LossFunction, backward, clip, optimizer step on one batch dictionary (trainer.py:395-434)."""
         self.model.train()
         batch = self._move_batch_to_device(batch)
+        if self.use_hip_graph:
+            host = self._graph_step(batch)
+            if host is not None:
+                return host
         out, losses = self._batch_losses(batch)
         self.optimizer.zero_grad()
-        losses["total_loss"].backward()
+        arena = _hip.step_arena(self)
+        if arena is not None:
+            arena.begin_step()
+        try:
+            losses["total_loss"].backward()
+        finally:
+            if arena is not None:
+                arena.end_step()
         if self.grad_sync is not None:
             self.grad_sync(self.model)
         clip = self.config.training.gradient_clip_norm

@@ -372,3 +372,50 @@ def test_sharded_streams_two_ranks_uneven_arrivals_match_the_union_batches():
             # tensors agree far more closely
             d = (a["params"][k].double() - rsd[k].detach().double()).abs()
             assert float(d.max()) <= 2.1e-3 and float(d.mean()) <= 5e-4, (k, float(d.max()), float(d.mean()))
+
+
+def test_trainer_recorded_step_equals_the_eager_one():
+    """Trainer.use_hip_graph: the third train_step with one batch signature is recorded (forward with intermediates,
+    LossFunction with its consistency term against the previous batch, backward, clip + Adam) and replayed afterwards.
+    Against a second trainer that launches every step eagerly, over a sequence with a ragged batch in the middle (that
+    step and the one after it - which has no predecessor of its shape - run eagerly in both): the same loss dictionaries
+    step by step and the same parameters at the end."""
+    import ocean
+    from ocean.data import ServiceGraph
+    from ocean.models.training import Trainer
+    sg = ServiceGraph(synth.random_digraph(6, 2.0, 1), torch.randn(6, 7, generator=torch.Generator().manual_seed(3)))
+
+    def batch(seed, B=4):
+        g = torch.Generator().manual_seed(seed)
+        lab = torch.zeros(B, 6)
+        lab[torch.arange(B), torch.randint(0, 6, (B,), generator=g)] = 1
+        return {"metrics": torch.randn(B, 8, 5, generator=g), "logs": torch.randn(B, 24, generator=g), "labels": lab,
+                "graphs": [sg] * B, "timestamps": [datetime(2024, 1, 1)] * B}
+
+    trainers = []
+    for use_graph in (True, False):
+        cfg = tiny_config()
+        m = ocean.OCEANModel(cfg)
+        zero_dropout(m)
+        m.load_state_dict(synth.fill_state_dict(m.state_dict(), 5))
+        m.contrastive_negatives = "in_batch"
+        tr = Trainer(m, cfg, data_loader=None)
+        tr.use_hip_graph = use_graph
+        trainers.append(tr)
+    sizes = [4, 4, 4, 4, 4, 4, 3, 4, 4, 4, 4]
+    for i, B in enumerate(sizes):
+        if i == 8:
+            for tr in trainers:
+                tr.optimizer.param_groups[0]["lr"] = 3e-4          # the epoch scheduler's change must reach the replays
+        a, b = (tr.train_step(batch(100 + i, B)) for tr in trainers)
+        assert set(a) == set(b)
+        for k in b:
+            tol = 1e-5 if i < 5 else 2e-3          # Adam amplifies the atomics' rounding noise over the steps
+            assert abs(a[k] - b[k]) <= tol * max(abs(b[k]), 1e-3), (i, k, a[k], b[k])
+        if B == 4 and i not in (0, 7):
+            assert a["consistency_loss"] > 0.0
+    assert len(trainers[0]._graphed) == 1 and not trainers[1]._graphed
+    st = trainers[0].optimizer.state
+    assert {int(s["step"]) for s in st.values() if s} == {len(sizes)}
+    for p, q in zip(trainers[0].model.parameters(), trainers[1].model.parameters()):
+        close(p, q, 2e-3)

@@ -2,11 +2,12 @@
 
   C1  README example (5 services, batch 1, seq_len 10, logs [1,10,768]): eval forward latency
   P   predict_root_cause on 32 windows of the headline shape: serving latency
+  T   Trainer.train_step at batch 32 of the headline shape: samples/s
   C2  online step, 64 services, batch 256, seq_len 64, in-batch InfoNCE: samples/s
   C4  4096 services (CSR GAT, in-degree 8), batch 64 = one GPU's share of the 512 global batch: samples/s
   C5  per-window online updates (64 services, seq_len 64): update latency p50 / p99 for window batches of 8
 
-    python tools/bench_configs.py [C1 P C2 C4 C5]
+    python tools/bench_configs.py [C1 P T C2 C4 C5]
 
 Prints one JSON line per configuration.  Same synthetic-input recipe as bench.py.
 """
@@ -98,6 +99,28 @@ def train_cfg(name, N, S, deg, B, T, steps, use_graph=True):
             "batch": B, "seq_len": T, "services": N, "launch": "hip-graph replay" if learner._graphed else "eager"}
 
 
+def trainer_step(use_graph=True, B=32, N=256, T=128, steps=50):
+    """Trainer.train_step (LossFunction with consistency and diversity terms) at the reference's default batch size"""
+    from datetime import datetime
+    from ocean.models.training import Trainer
+    cfg, m, graph = make(N, N, 8.0)
+    m.contrastive_negatives = "in_batch"
+    tr = Trainer(m, cfg, data_loader=None)
+    tr.use_hip_graph = use_graph
+    metrics, logs, labels = inputs(B, T, N)
+    batch = {"metrics": metrics, "logs": logs, "labels": labels, "graphs": [graph] * B, "timestamps": [datetime(2024, 1, 1)] * B}
+    for _ in range(4):
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"config": f"Trainer.train_step ({N} services, batch {B}, seq_len {T})", "metric": "samples/sec training step", "unit": "samples/s",
+            "value": B / dt, "ms_per_step": dt * 1e3, "launch": "hip-graph replay" if tr._graphed else "eager"}
+
+
 def c5(use_graph=True):
     cfg, m, graph = make(64, 64, 4.0)
     m.contrastive_negatives = "in_batch"
@@ -110,13 +133,15 @@ def c5(use_graph=True):
             "samples_per_s": 8 / (sum(ts) / len(ts)), "launch": "hip-graph replay" if learner._graphed else "eager"}
 
 
-which = sys.argv[1:] or ["C1", "P", "C2", "C4", "C5"]
+which = sys.argv[1:] or ["C1", "P", "T", "C2", "C4", "C5"]
 for w in which:
     for use_graph in (False, True):
         if w == "C1":
             r = c1(use_graph)
         elif w == "P":
             r = predict(use_graph)
+        elif w == "T":
+            r = trainer_step(use_graph)
         elif w == "C2":
             r = train_cfg("C2 online step (64 services, batch 256, seq_len 64, in-batch InfoNCE)", 64, 64, 4.0, 256, 64, 20, use_graph)
         elif w == "C4":
