@@ -234,3 +234,48 @@ def test_linear_layer_gradient_pair_refuses_overlap():
     _hip.linear_bwd(buf, dy.cuda(), w.cuda(), dw, None, buf, M, N, K)
     _close(dw, dy.double().t() @ x.double(), tol=4e-5)
     _close(buf, dy.double() @ w.double())
+
+
+def test_small_batch_conv_products_random_shapes():
+    """The convolution-shaped products of small batches (fewer than 256 64x64 output blocks: the few-tile kernel's
+    variant with taps) across seeded random shapes - 1, 3 or 5 taps, dilations up to beyond the sample length, sample
+    lengths that are not multiples of 32, output widths that leave partial tiles, both weight layouts, reductions short
+    and long enough for the eight-wave split - against a float64 reference computed on the device."""
+    from ocean import _hip
+    rng = torch.Generator().manual_seed(4321)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    pick = lambda xs: xs[ri(0, len(xs) - 1)]
+    for case in range(24):
+        T = pick([10, 12, 32, 50, 64, 128])
+        B = ri(1, max(1, 600 // T))
+        M = B * T
+        Cin, Cout = 4 * ri(8, 130), ri(5, 300)
+        if (M + 63) // 64 * ((Cout + 63) // 64) >= 256:
+            Cout = 64
+        taps = pick([1, 3, 3, 5])
+        d = ri(1, 40)
+        flip = bool(ri(0, 1))
+        b_kn = bool(ri(0, 1))
+        x = torch.randn(M, Cin, generator=rng).cuda()
+        w = (torch.randn(taps, Cout, Cin, generator=rng) * 0.1).cuda()            # [tap][n][k]
+        wk = w.transpose(1, 2).contiguous() if b_kn else w                          # [tap][k][n]
+        out = torch.full((M, Cout), float("nan"), device="cuda")
+        half = taps // 2
+        s0, st = (half * d, -d) if flip else (-half * d, d)
+        rc = _hip.lib().ocean_conv_gemm_f32(x.data_ptr(), Cin, wk.data_ptr(), Cout if b_kn else Cin, out.data_ptr(), Cout, M, Cout, Cin, 0,
+                                            int(b_kn), taps, T, s0, st, Cout * Cin, 0, 1, _hip.stream())
+        assert rc == 0, (case, rc)
+        xs = x.double().view(B, T, Cin)
+        ref = torch.zeros(B, T, Cout, dtype=torch.float64, device="cuda")
+        for t in range(taps):
+            s = s0 + t * st
+            sh = torch.zeros_like(xs)
+            if abs(s) >= T:
+                pass
+            elif s >= 0:
+                sh[:, :T - s] = xs[:, s:]
+            else:
+                sh[:, -s:] = xs[:, :T + s]
+            ref += sh @ w[t].double().t()
+        err = (out.double() - ref.view(M, Cout)).abs().max().item()
+        assert err <= 2e-5 * max(ref.abs().max().item(), 1.0), (case, T, B, Cin, Cout, taps, d, flip, b_kn, err)
