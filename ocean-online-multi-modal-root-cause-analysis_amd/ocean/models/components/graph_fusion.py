@@ -64,6 +64,11 @@ class InfoNCELoss(nn.Module):
         return loss * anchor.shape[0] if self.reduction == "sum" else loss
 
 
+def _no_row_offset(local_rows: int) -> int:
+    """A single process holds the whole batch: its rows start at 0 (a module-level function, so the module pickles)."""
+    return 0
+
+
 class ContrastiveLearningModule(nn.Module):
     def __init__(self, modality_dims: Dict[str, int], projection_dim: int = 256, temperature: float = 0.1,
                  num_negatives: int = 16):
@@ -76,7 +81,7 @@ class ContrastiveLearningModule(nn.Module):
         self.negatives = "bank"                    # or "in_batch"
         # data-parallel hooks (in-batch negatives): gather [B_loc,P] -> [B_glob,P] keeping autograd, and this rank's row offset
         self.gather_positives: Optional[Callable[[torch.Tensor], torch.Tensor]] = None
-        self.rank_row_offset: Callable[[int], int] = lambda local_rows: 0
+        self.rank_row_offset: Callable[[int], int] = _no_row_offset
         # data-parallel hook (memory-bank negatives): [M, B_loc, P] -> [M, B_all, P], the projections of every rank in
         # rank order, so that each rank writes the whole batch's rows into its copy of the ring and the copies stay equal
         self.gather_bank_rows: Optional[Callable[[torch.Tensor], torch.Tensor]] = None

@@ -134,6 +134,14 @@ class OCEANModel(nn.Module):
         self._graphed_fwd: Dict[Any, _GraphedForward] = {}
         self._graph_fwd_seen: Dict[Any, int] = {}
 
+    def __getstate__(self):
+        """Copies and pickles of the module carry parameters, buffers and settings, not this process's device-side
+        caches (recorded forward passes, side streams, the module list)."""
+        state = dict(self.__dict__)
+        state["_graphed_fwd"], state["_graph_fwd_seen"], state["_side_streams"] = {}, {}, {}
+        state.pop("_all_modules", None)
+        return state
+
     # ------------------------------------------------------------------ helpers
     @property
     def device(self) -> torch.device:

@@ -253,3 +253,20 @@ def test_bench_rank_launcher_stops_the_other_ranks_when_one_fails(monkeypatch):
     assert bench.launch_ranks(3, []) == 3
     assert time.time() - t0 < 20
     assert sorted(seen) == [(0, "3", "127.0.0.1"), (1, "3", "127.0.0.1"), (2, "3", "127.0.0.1")]
+
+
+def test_model_copies_do_not_carry_device_caches():
+    """copy.deepcopy / pickle of an OCEANModel keep the 201 state_dict entries and the settings, and start with empty
+    recording caches (a recorded HIP graph belongs to the process and the tensors it was recorded on)."""
+    import copy
+    import pickle
+    import ocean
+    m = ocean.OCEANModel(ocean.default_config())
+    m.use_hip_graph = True
+    m._graphed_fwd["stand-in"] = object()
+    m._graph_fwd_seen["stand-in"] = 2
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        assert list(clone.state_dict()) == list(m.state_dict())
+        assert clone.use_hip_graph is True and clone._graphed_fwd == {} and clone._graph_fwd_seen == {}
+        for (k, a), (_, b) in zip(m.state_dict().items(), clone.state_dict().items()):
+            assert torch.equal(a, b), k
