@@ -317,3 +317,33 @@ def test_headline_shape_full_size_matches_oracle():
     assert set(tk) <= set(got)
     for k in tk:
         close(got[k], rsd[k].grad, 1e-3, k)
+
+
+def test_eval_outputs_do_not_depend_on_batch_composition_or_order():
+    """At the headline shape (1024 x 128 x 256 services) in eval mode a sample's probabilities depend on that sample alone:
+    the rows of the full batch equal the same samples run as batches of 1, 8 and 128 (which take the few-tile kernels
+    where the full batch takes the large-tile ones) and the same samples in another order, to the 1e-4 relative bound
+    the probabilities are held to against the reference, with identical top-5 rankings."""
+    import ocean
+    from ocean.data import ServiceGraph
+    N, B, T = 256, 1024, 128
+    cfg = ocean.default_config()
+    cfg.model.num_services = N
+    m = ocean.OCEANModel(cfg)
+    m.load_state_dict(synth.fill_state_dict(m.state_dict(), 43))
+    m = m.cuda().eval()
+    gen = torch.Generator().manual_seed(10)
+    sg = ServiceGraph(synth.random_digraph(N, 8.0, 12), torch.randn(N, 12, generator=gen))
+    metrics, logs = torch.randn(B, T, 12, generator=gen).cuda(), torch.randn(B, 768, generator=gen).cuda()
+    with torch.no_grad():
+        full = m(metrics, sg, logs)["root_cause_probs"]
+        assert float(full.min()) > 0.0 and float(full.max()) < 1.0 and bool(torch.isfinite(full).all())
+        top = torch.topk(full, 5, dim=-1).indices
+        for lo, n in ((0, 1), (17, 1), (40, 8), (512, 128)):
+            part = m(metrics[lo:lo + n], sg, logs[lo:lo + n])["root_cause_probs"]
+            ref = full[lo:lo + n]
+            assert ((part - ref).abs() / ref).max().item() < 1e-4, (lo, n)
+            assert torch.equal(torch.topk(part, 5, dim=-1).indices, top[lo:lo + n]), (lo, n)
+        perm = torch.randperm(B, generator=gen).cuda()
+        shuffled = m(metrics[perm], sg, logs[perm])["root_cause_probs"]
+        assert ((shuffled - full[perm]).abs() / full[perm]).max().item() < 1e-4
