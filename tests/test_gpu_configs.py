@@ -347,3 +347,41 @@ def test_eval_outputs_do_not_depend_on_batch_composition_or_order():
         perm = torch.randperm(B, generator=gen).cuda()
         shuffled = m(metrics[perm], sg, logs[perm])["root_cause_probs"]
         assert ((shuffled - full[perm]).abs() / full[perm]).max().item() < 1e-4
+
+
+def test_headline_shape_replayed_step_equals_the_eager_one():
+    """Batch 1024 x 128 timesteps x 256 services, dropout 0: five update steps through OnlineLearner with the step
+    recorded as a HIP graph on the third, against a second learner launching every kernel from the host - the same losses
+    step by step (the first four to 1e-5: same kernels in the same order, differences only from atomics' order) and the
+    same parameters afterwards within what Adam makes of that noise."""
+    import ocean
+    from ocean.data import ServiceGraph
+    from ocean.models.training import OnlineLearner
+    N, B, T = 256, 1024, 128
+    gen = torch.Generator().manual_seed(21)
+    sg = ServiceGraph(synth.random_digraph(N, 8.0, 13), torch.randn(N, 12, generator=gen))
+    batches = []
+    for _ in range(5):
+        labels = torch.zeros(B, N)
+        labels[torch.arange(B), torch.randint(0, N, (B,), generator=gen)] = 1.0
+        batches.append((torch.randn(B, T, 12, generator=gen).cuda(), torch.randn(B, 768, generator=gen).cuda(), labels.cuda()))
+    runs = []
+    for use_graph in (True, False):
+        cfg = ocean.default_config()
+        cfg.model.num_services = N
+        m = ocean.OCEANModel(cfg)
+        zero_dropout(m)
+        m.load_state_dict(synth.fill_state_dict(m.state_dict(), 44))
+        m = m.cuda()
+        m.contrastive_negatives = "in_batch"
+        learner = OnlineLearner(m, cfg)
+        learner.use_hip_graph = use_graph
+        losses = [learner.process_tensors(x, sg, l, y)["batch_loss"] for x, l, y in batches]
+        assert bool(learner._graphed) == use_graph
+        runs.append((losses, [p.detach().clone() for p in m.parameters()]))
+        del learner, m
+        torch.cuda.empty_cache()
+    for i, (a, b) in enumerate(zip(runs[0][0], runs[1][0])):
+        assert abs(a - b) <= (1e-5 if i < 4 else 1e-3) * abs(b), (i, a, b)
+    for p, q in zip(runs[0][1], runs[1][1]):
+        close(p, q, 5e-3)           # five Adam steps of lr 1e-3 on elements whose gradient is rounding noise differ by up to 2 lr each
