@@ -364,6 +364,17 @@ def zero_grads_like(params, skip=None):
     return out
 
 
+def capture(graph: "torch.cuda.CUDAGraph"):
+    """torch.cuda.graph(graph) in thread-local capture mode.  In the default (global) mode the HIP runtime refuses
+    potentially unsafe calls from EVERY thread while the stream is capturing; the RCCL process group's watchdog thread
+    queries the events of earlier collectives on its own schedule, gets hipErrorStreamCaptureUnsupported when that falls
+    into a capture, and takes the process down (seen about once in ten recordings of a data-parallel step).  Other
+    threads of an application - a loader pinning memory, a copy - are in the same position.  The recorded work itself
+    is launched from this thread and from the autograd engine's worker onto the capturing stream and is captured
+    either way; the mode only decides whose unrelated calls are refused."""
+    return torch.cuda.graph(graph, capture_error_mode="thread_local")
+
+
 def stream() -> c_void_p:
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 

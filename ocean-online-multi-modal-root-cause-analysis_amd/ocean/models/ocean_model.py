@@ -77,7 +77,7 @@ class _GraphedForward:
         self.service_graph = service_graph
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        with _hip.capture(self.graph), torch.no_grad():
             self.outputs = model._forward_impl(self.metrics, service_graph, self.logs, False)
 
     def replay(self, metrics, logs) -> Dict[str, Any]:

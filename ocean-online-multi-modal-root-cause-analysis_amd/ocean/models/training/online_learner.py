@@ -163,9 +163,12 @@ class _GraphedStep:
         opt.settle()
         one = learner._one()
         arena = learner._grad_arena()
+        transport = getattr(learner.data_parallel, "transport", None)
+        if transport is not None and hasattr(transport, "quiesce"):
+            transport.quiesce()                        # no collective of the eager steps is still being watched
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with _hip.capture(self.graph):
             self.epoch.add_(1)
             outputs = model(self.metrics, service_graph, self.logs)
             losses = model.compute_loss(outputs, self.labels)

@@ -154,9 +154,12 @@ class _GraphedTrainStep:
         opt.zero_grad(set_to_none=True)
         opt.settle()
         arena = _hip.step_arena(trainer)
+        transport = getattr(trainer.data_parallel, "transport", None)
+        if transport is not None and hasattr(transport, "quiesce"):
+            transport.quiesce()                        # no collective of the eager steps is still being watched
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with _hip.capture(self.graph):
             self.epoch.add_(1)
             out = model(self.metrics, self.service_graph, self.logs, return_intermediate=True)
             temporal = out["intermediate"]["temporal_features"]

@@ -25,6 +25,7 @@ takes part with weight 0.
 from __future__ import annotations
 
 import os
+import time
 from typing import List, Optional
 
 import torch
@@ -74,6 +75,16 @@ class Transport:
 
     def barrier(self) -> None:
         dist.barrier(group=self.group)
+
+    def quiesce(self) -> None:
+        """Before a step with collectives is recorded into a HIP graph: wait until the process group's watchdog thread has
+        retired every collective issued so far.  The watchdog polls the events of pending collectives on its own
+        schedule (it wakes at least every 100 ms); a poll that falls into a stream capture is refused by the HIP runtime,
+        the exception ends the watchdog thread and with it the process (seen about once in ten recordings).  There is no
+        call that waits for its list to empty, so: finish the device's work, then give it three of its periods."""
+        if self.backend == "nccl":
+            torch.cuda.synchronize()
+            time.sleep(0.3)
 
 
 class _ThenScale:

@@ -160,7 +160,7 @@ def test_checkpoints_load_under_the_restricted_unpickler(tmp_path):
     r2 = l2.process_tensors(b3[0], sg, b3[1], b3[2])
     assert abs(r1["batch_loss"] - r2["batch_loss"]) < 1e-6
     for a, b in zip(m.parameters(), m2.parameters()):
-        close(a, b, 1e-6)
+        close(a, b, 1e-5)           # two runs of one step differ by the atomics' order (~1e-6); a state that was not restored differs by ~lr = 1e-3
     # Trainer
     cfg.training.checkpoint_dir = str(tmp_path / "ck")
     tr = Trainer(m, cfg, data_loader=None)
