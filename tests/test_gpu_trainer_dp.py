@@ -419,3 +419,68 @@ def test_trainer_recorded_step_equals_the_eager_one():
     assert {int(s["step"]) for s in st.values() if s} == {len(sizes)}
     for p, q in zip(trainers[0].model.parameters(), trainers[1].model.parameters()):
         close(p, q, 2e-3)
+
+
+def _dp_variants_worker(rank, world, port, fix, out):
+    import faulthandler
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(120, exit=True)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        import ocean
+        from ocean import _hip
+        from ocean.data import ServiceGraph
+        from ocean.models.training import OnlineLearner, Trainer
+        from ocean.parallel import DataParallel
+        cfg = tiny_config()
+        sg = ServiceGraph(fix["adj"], fix["nf"])
+        B = fix["metrics"].shape[0]
+        batch = {"metrics": fix["metrics"], "logs": fix["logs"], "labels": fix["labels"], "graphs": [sg] * B}
+        res = {}
+        for variant in ("bank_learner", "trainer"):
+            for mode in ("eager", "graph"):
+                m = ocean.OCEANModel(cfg)
+                zero_dropout(m)
+                m.load_state_dict({k: v.clone() for k, v in fix["sd"].items()})
+                m = m.cuda()
+                if variant == "bank_learner":
+                    m.contrastive_negatives = "bank"
+                    owner = OnlineLearner(m, cfg)
+                    step = lambda: owner.process_tensors(fix["metrics"], sg, fix["logs"], fix["labels"])["batch_loss"]
+                else:
+                    m.contrastive_negatives = "in_batch"
+                    owner = Trainer(m, cfg, data_loader=None)
+                    step = lambda: owner.train_step(batch)["total_loss"]
+                dp = DataParallel(m, owner)
+                owner.use_hip_graph = mode == "graph"
+                hist = [step() for _ in range(6)]
+                cm = m.fusion_module.contrastive_module
+                res[(variant, mode)] = {"hist": hist, "params": [p.detach().cpu() for p in m.parameters()],
+                                        "recorded": len(owner._graphed), "bank": cm.memory_bank.detach().cpu(), "ptr": int(cm.memory_ptr)}
+                _hip.unregister_grad_arena(dp.arena)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rccl_rank_records_the_bank_mode_step_and_the_trainer_step():
+    """With an RCCL process group attached (one rank: all a one-GPU box can host) the update step in memory-bank mode (the
+    gathered projections written into the ring on the device) and Trainer.train_step (diversity rows gathered) are
+    recorded with their collectives inside the HIP graph and give the eager runs' losses, parameters, bank and pointer."""
+    import torch.multiprocessing as mp
+    fix = _fixture()
+    ctx = mp.get_context("spawn")
+    out = ctx.Manager().dict()
+    mp.spawn(_dp_variants_worker, args=(1, _free_port(), fix, out), nprocs=1, join=True)
+    r = out[0]
+    for variant in ("bank_learner", "trainer"):
+        e, g = r[(variant, "eager")], r[(variant, "graph")]
+        assert e["recorded"] == 0 and g["recorded"] == 1, variant
+        for a, b in zip(e["hist"], g["hist"]):
+            assert abs(a - b) <= 1e-4 * abs(a), (variant, e["hist"], g["hist"])
+        for a, b in zip(e["params"], g["params"]):
+            close(b, a, 3e-3)
+        assert e["ptr"] == g["ptr"], variant
+        close(g["bank"], e["bank"], 1e-3)
