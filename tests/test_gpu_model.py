@@ -377,3 +377,82 @@ def test_three_pair_infonce_with_gathered_positives_equals_per_pair_calls():
     close(gg.grad, gs.grad, 1e-4)
     with pytest.raises(ValueError):
         ops.infonce_pairs(zg, 0.1, gathered=gg, label_offset=Ball)      # rows would fall outside the gathered set
+
+
+def test_random_small_architectures_and_shapes_match_oracle():
+    """Seeded random architectures (block counts and widths, dilations, head counts, feature widths) and input shapes
+    (batches from 1, windows from 1 timestep, graphs from one isolated service, token-sequence and absent logs) through
+    one training forward + backward in both negative modes against the oracle: probabilities 1e-4 relative, identical
+    top-k, losses and every gradient 1e-3."""
+    import ocean
+    from ocean.data import ServiceGraph
+    from oracle import ocean_ref as R
+    rng = torch.Generator().manual_seed(2718)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    pick = lambda xs: xs[ri(0, len(xs) - 1)]
+    for case in range(32):
+        L = ri(1, 4)
+        cfg = ocean.OCEANConfig()
+        cfg.model.dcnn_channels = [4 * ri(1, 6) for _ in range(L)]
+        cfg.model.dcnn_dilation_rates = [pick([1, 2, 3, 4, 8]) for _ in range(L)]
+        gh, ah = pick([1, 2, 4]), pick([1, 2, 4])
+        hidden = 8 * ri(1, 3) * max(gh, ah)         # the fusion stage takes the graph features at the attention width
+        cfg.model.hidden_dim = hidden               # (ocean_model.py:87-101), so the two widths are one
+        cfg.model.attention_dim = hidden
+        cfg.model.attention_num_heads, cfg.model.gnn_num_heads = ah, gh
+        cfg.model.gnn_num_layers = ri(1, 3)
+        cfg.model.fusion_projection_dim = 16 * ri(1, 3)
+        S = ri(1, 9)
+        cfg.model.num_services = S
+        F, LD, GF = ri(1, 13), 4 * ri(1, 8), ri(1, 9)
+        cfg.data.metrics_features, cfg.data.log_embedding_dim, cfg.data.graph_features = F, LD, GF
+        B, Tn = pick([1, 1, 2, 3, 5, 8]), pick([1, 2, 3, 7, 10, 16])
+        negatives = pick(["in_batch", "bank"])
+        m = ocean.OCEANModel(cfg)
+        zero_dropout(m)
+        sd = synth.fill_state_dict(m.state_dict(), 100 + case)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        m.contrastive_negatives = negatives
+        adj = (torch.rand(S, S, generator=rng) < 0.4).float()
+        adj.fill_diagonal_(0.0)
+        nf = torch.randn(S, GF, generator=rng)
+        metrics = torch.randn(B, Tn, F, generator=rng)
+        logs_kind = pick(["vector", "vector", "tokens", "none"])
+        logs = None if logs_kind == "none" else (torch.randn(B, LD, generator=rng) if logs_kind == "vector" else torch.randn(B, 3, LD, generator=rng))
+        labels = torch.zeros(B, S)
+        labels[torch.arange(B), torch.randint(0, S, (B,), generator=rng)] = 1.0
+        what = (case, cfg.model.dcnn_channels, cfg.model.dcnn_dilation_rates, gh, ah, hidden, cfg.model.attention_dim, S, F, LD, GF, B, Tn, negatives, logs_kind)
+        rsd = R.require_grad(sd)
+        if B * Tn == 1:
+            # one value per channel: BatchNorm refuses to train on it, in the reference (torch) and here alike
+            with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+                R.model_forward(rsd, metrics, adj, nf, logs, training=True, negatives=negatives, dilations=tuple(cfg.model.dcnn_dilation_rates),
+                                gnn_heads=gh, gnn_layers=cfg.model.gnn_num_layers, fusion_heads=8, log_dim=LD)
+            with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+                m(metrics, ServiceGraph(adj, nf), logs)
+            continue
+        ro = R.model_forward(rsd, metrics, adj, nf, logs, training=True, negatives=negatives, dilations=tuple(cfg.model.dcnn_dilation_rates),
+                             gnn_heads=gh, gnn_layers=cfg.model.gnn_num_layers, fusion_heads=8, log_dim=LD)
+        rl = R.compute_loss(ro, labels)
+        rl["total_loss"].backward()
+        out = m(metrics, ServiceGraph(adj, nf), logs)
+        losses = m.compute_loss(out, labels.cuda())
+        losses["total_loss"].backward()
+        probs, rprobs = out["root_cause_probs"].detach().cpu(), ro["root_cause_probs"].detach()
+        assert ((probs - rprobs).abs() / rprobs).max().item() < 1e-4, what
+        k = min(3, S)
+        assert torch.equal(torch.topk(probs, k, dim=-1).indices, torch.topk(rprobs, k, dim=-1).indices), what
+        for name in ("total_loss", "prediction_loss", "contrastive_loss"):
+            try:
+                close(losses[name], rl[name], 1e-3)
+            except AssertionError as e:
+                raise AssertionError(f"{what} {name}: {e}")
+        for name, p in m.named_parameters():
+            if rsd[name].grad is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, (what, name)
+            else:
+                try:
+                    close(p.grad, rsd[name].grad, 1e-3)
+                except AssertionError as e:
+                    raise AssertionError(f"{what} {name}: {e}")
