@@ -239,6 +239,26 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* temporal, const f
                      const float* d_processed /* or NULL */, const float* d_projections /* or NULL */,
                      float* const* grads, float* d_temporal, float* d_spatial, float* d_logs, void* stream);
 
+/* One ProjectionHead called on its own (ProjectionHead.forward, graph_fusion.py:77-92, as
+ * ContrastiveLearningModule.forward calls it per modality, :217-221): y = normalize(W1 . dropout(relu(W0 x + b0)) + b1),
+ * two layers with ReLU (the reference's default); normalize == 0 leaves the last Linear's output as it is.
+ * params / grads: {0.weight [hidden,in], 0.bias, 3.weight [out,hidden], 3.bias}; gradients are ADDED to grads
+ * (NULL entries are skipped together with their data gradient's layer only when both are NULL); dx may be NULL. */
+typedef struct {
+  int B, in_dim, hidden, out_dim;
+  int training, normalize;
+  float dropout;
+  uint64_t seed;
+  const uint64_t* seed_epoch;
+} ocean_proj_shape;
+size_t ocean_projection_head_fwd_workspace(const ocean_proj_shape* s);
+size_t ocean_projection_head_bwd_workspace(const ocean_proj_shape* s);
+int ocean_projection_head_fwd(const ocean_proj_shape* s, const float* x, float* const* params, float* ws, size_t ws_floats,
+                              float* y /* [B,out] */, void* stream);
+int ocean_projection_head_bwd(const ocean_proj_shape* s, const float* x, float* const* params, const float* ws_fwd,
+                              const float* y, const float* dy, float* ws_bwd, size_t ws_bwd_floats, float* const* grads,
+                              float* dx /* [B,in] or NULL */, void* stream);
+
 /* ------------------------------------------------------------------ InfoNCE
  * Replaces InfoNCELoss.forward (graph_fusion.py:112-162) and backward.
  * K > 0: memory-bank branch, logits = [a.p, a.n_1 .. a.n_K]/tau, label 0 (Bp == B).

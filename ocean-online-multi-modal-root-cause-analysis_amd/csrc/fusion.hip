@@ -402,4 +402,67 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* s
   return OCEAN_OK;
 }
 
+// ---- one ProjectionHead called on its own: Linear -> ReLU -> Dropout -> Linear -> L2 normalise.
+// Forward workspace: h [B, hidden] (after ReLU and dropout) | z [B, out] (before normalising) | norms [B].
+namespace {
+struct ProjPlan { size_t H, Z, nrm, fwd_total, dZ, dH, bwd_total; };
+int proj_plan(const ocean_proj_shape* s, ProjPlan* p) {
+  if (!s) return OCEAN_ERR_NULL;
+  if (s->B <= 0 || s->in_dim <= 0 || s->hidden <= 0 || s->out_dim <= 0) return OCEAN_ERR_BAD_SHAPE;
+  if (s->dropout < 0.f || s->dropout >= 1.f) return OCEAN_ERR_BAD_SHAPE;
+  const size_t B = s->B;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o = al4(o + n); return r; };
+  p->H = take(B * s->hidden); p->Z = take(B * s->out_dim); p->nrm = take(B);
+  p->fwd_total = o;
+  o = 0;
+  p->dZ = take(B * s->out_dim); p->dH = take(B * s->hidden);
+  p->bwd_total = o;
+  return OCEAN_OK;
+}
+DropoutP proj_site(const ocean_proj_shape* s) {
+  DropoutP d;
+  d.p = s->training ? s->dropout : 0.f;
+  d.seed = s->seed;
+  d.epoch = s->seed_epoch;
+  return d;
+}
+}  // namespace
+
+size_t ocean_projection_head_fwd_workspace(const ocean_proj_shape* s) { ProjPlan p; return proj_plan(s, &p) == OCEAN_OK ? p.fwd_total : 0; }
+size_t ocean_projection_head_bwd_workspace(const ocean_proj_shape* s) { ProjPlan p; return proj_plan(s, &p) == OCEAN_OK ? p.bwd_total : 0; }
+
+int ocean_projection_head_fwd(const ocean_proj_shape* s, const float* x, float* const* P_, float* ws, size_t ws_floats, float* y,
+                              void* stream) {
+  ProjPlan pl;
+  OCEAN_TRY(proj_plan(s, &pl));
+  if (!x || !P_ || !ws || !y) return OCEAN_ERR_NULL;
+  if (ws_floats < pl.fwd_total) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const DropoutP d = proj_site(s);
+  Epi e; e.drop = &d;
+  OCEAN_TRY(linear_fwd(x, s->in_dim, P_[0], P_[1], ws + pl.H, s->hidden, s->B, s->hidden, s->in_dim, 1, st, d.p > 0.f ? &e : nullptr));
+  if (!s->normalize) return linear_fwd(ws + pl.H, s->hidden, P_[2], P_[3], y, s->out_dim, s->B, s->out_dim, s->hidden, 0, st);
+  OCEAN_TRY(linear_fwd(ws + pl.H, s->hidden, P_[2], P_[3], ws + pl.Z, s->out_dim, s->B, s->out_dim, s->hidden, 0, st));
+  return l2norm_fwd(ws + pl.Z, s->out_dim, y, s->out_dim, ws + pl.nrm, s->B, s->out_dim, 1e-12f, st);
+}
+
+int ocean_projection_head_bwd(const ocean_proj_shape* s, const float* x, float* const* P_, const float* wf, const float* y,
+                              const float* dy, float* wb, size_t wb_floats, float* const* G_, float* dx, void* stream) {
+  ProjPlan pl;
+  OCEAN_TRY(proj_plan(s, &pl));
+  if (!x || !P_ || !wf || !y || !dy || !wb || !G_) return OCEAN_ERR_NULL;
+  if (wb_floats < pl.bwd_total) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const float* dz = dy;
+  if (s->normalize) {
+    OCEAN_TRY(l2norm_bwd(dy, s->out_dim, y, s->out_dim, wf + pl.nrm, wb + pl.dZ, s->out_dim, s->B, s->out_dim, 1e-12f, st));
+    dz = wb + pl.dZ;
+  }
+  const DropoutP d = proj_site(s);
+  Epi e; e.drop = d.p > 0.f ? &d : nullptr; e.relu_mask = wf + pl.H; e.ld_mask = s->hidden;   // dropout and ReLU backward leaving the data gradient
+  OCEAN_TRY(lin_bwd(wf + pl.H, s->hidden, dz, s->out_dim, s->B, s->out_dim, s->hidden, P_[2], G_[2], G_[3], wb + pl.dH, s->hidden, 0, st, &e));
+  return lin_bwd(x, s->in_dim, wb + pl.dH, s->hidden, s->B, s->hidden, s->in_dim, P_[0], G_[0], G_[1], dx, s->in_dim, 0, st);
+}
+
 }  // extern "C"

@@ -96,6 +96,11 @@ class HeadShape(ctypes.Structure):
                 ("dropout", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
 
 
+class ProjShape(ctypes.Structure):
+    _fields_ = [("B", c_int), ("in_dim", c_int), ("hidden", c_int), ("out_dim", c_int), ("training", c_int),
+                ("normalize", c_int), ("dropout", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
+
+
 class AdamChunk(ctypes.Structure):
     _fields_ = [("param", c_uint64), ("grad", c_uint64), ("exp_avg", c_uint64), ("exp_avg_sq", c_uint64),
                 ("n", ctypes.c_int64)]
@@ -133,6 +138,11 @@ def _declare_rest(lib) -> None:
     sig("ocean_head_bwd_workspace", c_size_t, hp)
     sig("ocean_head_fwd", c_int, hp, vp, tp, vp, c_size_t, vp, vp, vp)
     sig("ocean_head_bwd", c_int, hp, vp, tp, vp, vp, c_size_t, vp, vp, vp, tp, vp, vp)
+    pp = POINTER(ProjShape)
+    sig("ocean_projection_head_fwd_workspace", c_size_t, pp)
+    sig("ocean_projection_head_bwd_workspace", c_size_t, pp)
+    sig("ocean_projection_head_fwd", c_int, pp, vp, tp, vp, c_size_t, vp, vp)
+    sig("ocean_projection_head_bwd", c_int, pp, vp, tp, vp, vp, vp, vp, c_size_t, tp, vp, vp)
     sig("ocean_bce_fwd", c_int, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_bce_bwd", c_int, vp, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_conv_gemm_f32", c_int, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_int, vp)

@@ -46,8 +46,58 @@ class ProjectionHead(nn.Module):
         self.normalize = True
         self.num_layers, self.activation_name = num_layers, activation
 
-    def forward(self, x):
-        raise NotImplementedError("ProjectionHead is executed inside GraphFusionModule's fused HIP driver")
+    def _two_layer_params(self):
+        lin = [m for m in self.projection if isinstance(m, nn.Linear)]
+        drop = [m for m in self.projection if isinstance(m, nn.Dropout)]
+        if self.num_layers != 2 or self.activation_name != "relu" or len(lin) != 2:
+            raise NotImplementedError("the HIP path implements the reference's default projection head: 2 layers with ReLU")
+        return [lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias], (drop[0].p if drop else 0.0)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """The head on its own (graph_fusion.py:77-92), as ContrastiveLearningModule.forward calls it per modality;
+        GraphFusionModule runs its three heads inside its fused driver instead."""
+        params, p = self._two_layer_params()
+        if x.dim() != 2 or x.shape[1] != params[0].shape[1]:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(x.shape)} and "
+                               f"{params[0].shape[1]}x{params[0].shape[0]})")
+        return _ProjectionFunction.apply(x.contiguous().float(), self, float(p), *params)
+
+
+class _ProjectionFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, p, *params):
+        L = _hip.lib()
+        sh = _hip.ProjShape()
+        sh.B, sh.in_dim, sh.hidden, sh.out_dim = x.shape[0], x.shape[1], params[0].shape[0], params[2].shape[0]
+        sh.training, sh.normalize = int(module.training), int(bool(module.normalize))
+        sh.dropout = p if module.training else 0.0
+        sh.seed = _hip.new_seed(sh.dropout)
+        sh.seed_epoch = _hip.seed_epoch(x.device).data_ptr() if sh.dropout > 0 else None
+        ctx.set_materialize_grads(False)
+        ws = torch.empty(L.ocean_projection_head_fwd_workspace(ctypes.byref(sh)), device=x.device, dtype=torch.float32)
+        y = torch.empty(sh.B, sh.out_dim, device=x.device, dtype=torch.float32)
+        _hip.check(L.ocean_projection_head_fwd(ctypes.byref(sh), _hip.dev_ptr(x, "x"), _hip.ptr_table(params, "projection param"),
+                                               _hip.dev_ptr(ws), ws.numel(), _hip.dev_ptr(y), _hip.stream()),
+                   "ocean_projection_head_fwd")
+        ctx.sh = sh
+        ctx.save_for_backward(x, ws, y, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return (None,) * (3 + 4)
+        L = _hip.lib()
+        x, ws, y, *params = ctx.saved_tensors
+        sh = ctx.sh
+        wb = torch.empty(L.ocean_projection_head_bwd_workspace(ctypes.byref(sh)), device=x.device, dtype=torch.float32)
+        grads = _hip.zero_grads_like(params)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        _hip.check(L.ocean_projection_head_bwd(ctypes.byref(sh), _hip.dev_ptr(x), _hip.ptr_table(params, "projection param"),
+                                               _hip.dev_ptr(ws), _hip.dev_ptr(y), _hip.dev_ptr(dy.contiguous()), _hip.dev_ptr(wb),
+                                               wb.numel(), _hip.ptr_table(grads, "projection grad"), _hip.dev_ptr(dx),
+                                               _hip.stream()), "ocean_projection_head_bwd")
+        return (dx, None, None) + tuple(g if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(grads))
 
 
 class InfoNCELoss(nn.Module):
@@ -152,9 +202,18 @@ class ContrastiveLearningModule(nn.Module):
                                                     _hip.dev_ptr(rows, "rows"), rows.shape[0], K, P, _hip.stream()),
                    "ocean_bank_ring_write")
 
-    def forward(self, modality_features, return_projections: bool = False):
-        raise NotImplementedError("projections are produced by GraphFusionModule's fused driver; "
-                                  "use losses_from_projections / _update_memory_bank")
+    def forward(self, modality_features: Dict[str, torch.Tensor], return_projections: bool = False) -> Dict[str, Any]:
+        """The module on its own (graph_fusion.py:204-245): every modality that has a head is projected, InfoNCE over
+        every pair of modalities (against the memory bank, or in-batch when `negatives` says so), then - in training -
+        the ring write.  GraphFusionModule does the same from the projections its fused driver produces."""
+        projections = {m: self.projection_heads[m](x) for m, x in modality_features.items() if m in self.projection_heads}
+        losses = self.losses_from_projections(projections)
+        if self.training and self.negatives == "bank":
+            self._update_memory_bank(projections)
+        results: Dict[str, Any] = {"losses": dict(losses)}
+        if return_projections:
+            results["projections"] = projections
+        return results
 
 
 class _FusionFunction(torch.autograd.Function):
