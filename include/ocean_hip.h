@@ -34,6 +34,15 @@ extern "C" {
 /* Library/ABI version: bumped when a signature changes. */
 int ocean_abi_version(void);
 
+/* Opt-in arithmetic for the large (full-tile) products of the convolutions: each fp32 operand is split into two bf16
+ * values (x = hi + lo) on its way into LDS and the product formed as hi.hi + hi.lo + lo.hi by three bf16 matrix
+ * instructions with fp32 accumulation - about 16 bits of each product instead of 24, at several times the fp32
+ * matrix rate.  Off by default (also: environment OCEAN_GEMM_SPLIT_BF16=1 at load time); process-wide; returns the
+ * previous setting.  Set it before a step is recorded into a HIP graph - a recording keeps the kernels it was made
+ * with.  No counterpart in the reference (torch fp32 on its device's default matmul path). */
+int ocean_set_split_bf16(int on);
+int ocean_get_split_bf16(void);
+
 /* ------------------------------------------------------------------ GEMM
  * C[M,N] = A . B (+bias)(+R)(ReLU).  fp32 in, fp32 accumulate on the matrix
  * cores.  a_kmajor: A stored [K][M] instead of [M][K]; b_kn: B stored [K][N]

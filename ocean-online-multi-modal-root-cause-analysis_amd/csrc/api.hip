@@ -1,10 +1,26 @@
 // Generic entry points of the C ABI (see include/ocean_hip.h).
 #include "../../include/ocean_hip.h"
 #include "ops.h"
+#include <atomic>
+#include <cstdlib>
+
+namespace {
+std::atomic<int>& split_flag() {
+  static std::atomic<int> f{getenv("OCEAN_GEMM_SPLIT_BF16") != nullptr && atoi(getenv("OCEAN_GEMM_SPLIT_BF16")) != 0 ? 1 : 0};
+  return f;
+}
+}  // namespace
+bool ocean_split_bf16() { return split_flag().load(std::memory_order_relaxed) != 0; }
 
 extern "C" {
 
 int ocean_abi_version(void) { return 1; }
+
+int ocean_set_split_bf16(int on) {
+  const int prev = split_flag().exchange(on ? 1 : 0, std::memory_order_relaxed);
+  return prev;
+}
+int ocean_get_split_bf16(void) { return ocean_split_bf16() ? 1 : 0; }
 
 int ocean_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                    int a_kmajor, int b_kn, const float* bias, const float* R, int ldr, int relu, void* stream) {

@@ -223,10 +223,219 @@ __global__ __launch_bounds__(kThreads, SEG == 4 ? 2 : 3) void gemm_nt_kernel(con
   epilogue_full<BM, BN, false, BNS>(acc, e, e.C, bn_drop, m0, n0, tile_m, wave, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same products with each fp32 operand split into two bf16 values, x = hi + lo (hi = bf16(x) rounded to nearest,
+// lo = bf16(x - hi)), and three bf16 matrix instructions per fp32 one's worth of work: hi.hi + hi.lo + lo.hi,
+// accumulated in fp32 (lo.lo, 2^-16 of the product, is dropped).  Opt-in (ocean_set_split_bf16): the results differ
+// from the fp32 kernel's in about the 16th bit of every product.
+//
+// Operands are split once, on their way into LDS.  A tile image keeps 64-byte rows: quads {hi k0-7, hi k8-15,
+// lo k0-7, lo k8-15}, swizzled as above; lane (m, h) reads quad h (and 2 + h) of row m with one ds_read_b128 each
+// and holds k = 8h .. 8h + 7 - the operand layout of v_mfma_f32_32x32x16_bf16 - so a 16-deep tile is one k-step:
+// 3 instructions of 8 passes per accumulator where the fp32 kernel issues 8 of 16 passes.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
+  hi.x = pack_bf16(v.x, v.y);
+  hi.y = pack_bf16(v.z, v.w);
+  lo.x = pack_bf16(v.x - __uint_as_float(hi.x << 16), v.y - __uint_as_float(hi.x & 0xffff0000u));
+  lo.y = pack_bf16(v.z - __uint_as_float(hi.y << 16), v.w - __uint_as_float(hi.y & 0xffff0000u));
+}
+
+template <int BN, int TAPS, bool BNS, int SEG = 1>
+__global__ __launch_bounds__(kThreads, SEG == 4 ? 2 : 3) void gemm_nt_bf3_kernel(const GemmBatch batch) {
+  const GemmP& p = batch.g[blockIdx.y];
+  constexpr int BM = 128, BK = 16;
+  constexpr int TM = 2, TN = BN / 64;
+  constexpr int A_SLOTS = TAPS == 3 ? 2 : 3, B_SLOTS = 3;
+  constexpr int TS = BM / SEG;
+  constexpr int A_ROWS = BM + (TAPS == 3 ? (SEG + 1) * kPad : 0);
+  auto win_row = [](int r) { return TAPS == 3 ? r + kPad * (1 + r / TS) : r; };
+  constexpr int A_SLOT_BYTES = A_ROWS * 64, B_SLOT_BYTES = BN * 64;
+  constexpr int A_PIECES = 2, B_PIECES = BN / 64;
+  __shared__ __align__(16) char smem[A_SLOTS * A_SLOT_BYTES + B_SLOTS * B_SLOT_BYTES];
+  char* const As = smem;
+  char* const Bs = smem + A_SLOTS * A_SLOT_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lm = lane & 31, h = lane >> 5;
+
+  const int tiles_n = p.N / BN, tiles_m = p.M / BM;
+  const int nwg = tiles_m * tiles_n;
+  if ((int)blockIdx.x >= nwg) return;
+  const int bid = xcd_swizzle(blockIdx.x, nwg);
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int n_chunks = p.K / BK;
+  const int n_iter = TAPS * n_chunks;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, 0x7FFFFFF0, 0x00020000);
+  constexpr unsigned kOob = 0x80000000u;
+  auto buf_load = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, int soff) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, soff, 0);
+    const unsigned x = r[0], y = r[1], z = r[2], w = r[3];
+    return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
+  };
+
+  // staging: piece i of a tile is k-values 4 kq .. + 3 of row (idx >> 2), idx = tid + 256 i; its hi halves go to
+  // 8 bytes of quad kq >> 1, its lo halves to the same place two quads further
+  unsigned a_goff[A_PIECES], a_loff[A_PIECES][2], b_goff[B_PIECES], b_loff[B_PIECES][2];
+#pragma unroll
+  for (int i = 0; i < A_PIECES; ++i) {
+    const int idx = tid + i * kThreads, row = idx >> 2, kq = idx & 3;
+    a_goff[i] = (unsigned)((m0 + row) * p.lda + kq * 4) * 4u;
+    a_loff[i][0] = img_off(win_row(row), kq >> 1) + (unsigned)(kq & 1) * 8u;
+    a_loff[i][1] = img_off(win_row(row), 2 + (kq >> 1)) + (unsigned)(kq & 1) * 8u;
+  }
+#pragma unroll
+  for (int i = 0; i < B_PIECES; ++i) {
+    const int idx = tid + i * kThreads, row = idx >> 2, kq = idx & 3;
+    b_goff[i] = (unsigned)((n0 + row) * p.ldb + kq * 4) * 4u;
+    b_loff[i][0] = img_off(row, kq >> 1) + (unsigned)(kq & 1) * 8u;
+    b_loff[i][1] = img_off(row, 2 + (kq >> 1)) + (unsigned)(kq & 1) * 8u;
+  }
+  float4 ra[A_PIECES], rb[B_PIECES];
+  auto load_a = [&](int chunk) {
+    const bool ok = chunk < n_chunks;
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) ra[i] = buf_load(rsrc_a, ok ? a_goff[i] : kOob, chunk * (BK * 4));
+  };
+  auto load_b = [&](int tap, int chunk) {
+    const bool ok = chunk < n_chunks;
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) rb[i] = buf_load(rsrc_b, ok ? b_goff[i] : kOob, (int)(tap * p.tap_stride_b + chunk * BK) * 4);
+  };
+  auto store_a = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+      uint2 hi, lo;
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<uint2*>(As + slot * A_SLOT_BYTES + a_loff[i][0]) = hi;
+      *reinterpret_cast<uint2*>(As + slot * A_SLOT_BYTES + a_loff[i][1]) = lo;
+    }
+  };
+  auto store_b = [&](int slot) {
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+      uint2 hi, lo;
+      split4(rb[i], hi, lo);
+      *reinterpret_cast<uint2*>(Bs + slot * B_SLOT_BYTES + b_loff[i][0]) = hi;
+      *reinterpret_cast<uint2*>(Bs + slot * B_SLOT_BYTES + b_loff[i][1]) = lo;
+    }
+  };
+
+  constexpr int A_SUB = (TAPS == 3 && SEG == 4) ? 4096 : 2048;
+  unsigned a_rd[TAPS][2], b_rd[2];         // [.][0]: hi quad, [.][1]: lo quad
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const int shift = TAPS == 3 ? p.shift0 + t * p.shift_step : 0;
+    const int r = win_row(wm * 64 + lm) + shift;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) a_rd[t][q] = img_off(r, 2 * q + h);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) b_rd[q] = img_off(wn * (BN / 2) + lm, 2 * q + h);
+
+  if (TAPS == 3) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int kBandQuads = (SEG + 1) * kPad * 4;
+    for (int idx = tid; idx < kBandQuads * A_SLOTS; idx += kThreads) {
+      const int slot = idx / kBandQuads, w = idx % kBandQuads;
+      const int band = (w >> 2) / kPad, r = band * (TS + kPad) + (w >> 2) % kPad;
+      *reinterpret_cast<float4*>(As + slot * A_SLOT_BYTES + r * 64 + (w & 3) * 16) = z;
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_a(0);
+  load_b(0, 0);
+  store_a(0);
+  store_b(0);
+  if (TAPS == 3) load_b(1, 0);
+  else { load_a(1); load_b(0, 1); }
+  __syncthreads();
+
+  // One 16-deep tile: its fragments are read, the registers holding tile it+1 go to their ring slots and are reloaded
+  // with tile it+2, twelve matrix instructions, barrier.  (The other blocks of the compute unit cover the LDS latency.)
+  int chunk = 0;
+  auto tile_step = [&](auto tap_c, auto aslot_c, auto bslot_c) {
+    constexpr int TAP = decltype(tap_c)::value, ASLOT = decltype(aslot_c)::value, BSLOT = decltype(bslot_c)::value;
+    constexpr int NB = (BSLOT + 1) % B_SLOTS;
+    constexpr bool NEXT_CHUNK = TAPS == 1 || TAP == 2;
+    constexpr int NA = NEXT_CHUNK ? (ASLOT + 1) % A_SLOTS : ASLOT;
+    uint4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const uint4*>(As + ASLOT * A_SLOT_BYTES + a_rd[TAP][q] + i * A_SUB);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const uint4*>(Bs + BSLOT * B_SLOT_BYTES + b_rd[q] + j * 2048);
+    }
+    store_b(NB);
+    if (TAPS == 3) load_b((TAP + 2) % 3, chunk + (TAP + 2) / 3);
+    else load_b(0, chunk + 2);
+    if (TAPS == 1) { store_a(NA); load_a(chunk + 2); }
+    else if (TAP == 2) store_a(NA);
+    else if (TAP == 1) load_a(chunk + 1);
+    // small terms first; the four accumulators separate dependent instructions
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+      const int qa = term == 0 ? 1 : 0, qb = term == 1 ? 1 : 0;        // lo.hi, hi.lo, hi.hi
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[qa][i]), __builtin_bit_cast(bf16x8, fb[qb][j]),
+                                                             acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (NEXT_CHUNK) ++chunk;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  int it = 0;
+  if constexpr (TAPS == 3) {
+    for (; it + 6 <= n_iter; it += 6) {
+      tile_step(I0{}, I0{}, I0{}); tile_step(I1{}, I0{}, I1{}); tile_step(I2{}, I0{}, I2{});
+      tile_step(I0{}, I1{}, I0{}); tile_step(I1{}, I1{}, I1{}); tile_step(I2{}, I1{}, I2{});
+    }
+    if (it < n_iter) { tile_step(I0{}, I0{}, I0{}); tile_step(I1{}, I0{}, I1{}); tile_step(I2{}, I0{}, I2{}); }
+  } else {
+    for (; it + 3 <= n_iter; it += 3) { tile_step(I0{}, I0{}, I0{}); tile_step(I0{}, I1{}, I1{}); tile_step(I0{}, I2{}, I2{}); }
+    if (it < n_iter) {
+      tile_step(I0{}, I0{}, I0{});
+      if (it + 1 < n_iter) tile_step(I0{}, I1{}, I1{});
+    }
+  }
+
+  const EpiArgs e = make_epi_args(p);
+  const DropoutP bn_drop = BNS ? dropout_resolve(p.bn_drop) : DropoutP{0.f, 0, nullptr};
+  epilogue_full<BM, BN, false, BNS>(acc, e, e.C, bn_drop, m0, n0, tile_m, wave, lane);
+}
+
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 template <int BN, int TAPS, int SEG = 1>
 void launch_nt(const GemmBatch& b, dim3 grid, hipStream_t stream) {
+  if (ocean_split_bf16()) {
+    if (b.g[0].bn_u != nullptr) hipLaunchKernelGGL((gemm_nt_bf3_kernel<BN, TAPS, true, SEG>), grid, dim3(kThreads), 0, stream, b);
+    else hipLaunchKernelGGL((gemm_nt_bf3_kernel<BN, TAPS, false, SEG>), grid, dim3(kThreads), 0, stream, b);
+    return;
+  }
   if (b.g[0].bn_u != nullptr) hipLaunchKernelGGL((gemm_nt_kernel<BN, TAPS, true, SEG>), grid, dim3(kThreads), 0, stream, b);
   else hipLaunchKernelGGL((gemm_nt_kernel<BN, TAPS, false, SEG>), grid, dim3(kThreads), 0, stream, b);
 }
@@ -269,7 +478,7 @@ int ocean_launch_gemm_nt(const GemmBatch& b, hipStream_t stream) {
   void* tok = nullptr;
   if (ocean_prof_on()) {
     char name[96];
-    snprintf(name, sizeof(name), "gemm_nt_kernel<%d,%d%s>", bn, p.taps, p.bn_u != nullptr ? ",bn-sums" : "");
+    snprintf(name, sizeof(name), "gemm_nt%s_kernel<%d,%d%s>", ocean_split_bf16() ? "_bf3" : "", bn, p.taps, p.bn_u != nullptr ? ",bn-sums" : "");
     double bytes = 4.0 * ((double)p.M * p.K + (double)p.N * p.K * p.taps + (double)p.M * p.N);
     if (p.R != nullptr) bytes += 4.0 * (p.r_bcast_T > 0 ? (double)p.M / p.r_bcast_T : (double)p.M) * p.N;
     if (p.bn_u != nullptr) bytes += 4.0 * (double)p.M * p.N;

@@ -169,6 +169,159 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_tn_kernel(const GemmBatch ba
   epilogue_full<BM, BN, true, false>(acc, e, Cz, DropoutP{0.f, 0, nullptr}, m0, n0, tile_m, wave, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same reduction on split operands (x = hi + lo in bf16, three bf16 matrix instructions per k-step: see
+// gemm_nt.hip).  A staging thread loads the same four columns of two consecutive rows k = 2j, 2j + 1 and packs each
+// column's pair into one dword, so a tile image is [8 row pairs][128 + 4 columns] dwords per half (hi, lo); lane (m, h)
+// reads the four dwords of row pairs 4h .. 4h + 3 of its column - rows k = 8h .. 8h + 7, the operand of
+// v_mfma_f32_32x32x16_bf16 - with four ds_read_b32 per half.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// columns c .. c + 3 of rows k (a) and k + 1 (b) -> per column one dword of hi halves {k, k + 1} and one of lo halves
+__device__ __forceinline__ void split_pair4(const float4& a, const float4& b, uint4& hi, uint4& lo) {
+  hi.x = pack_bf16(a.x, b.x); hi.y = pack_bf16(a.y, b.y); hi.z = pack_bf16(a.z, b.z); hi.w = pack_bf16(a.w, b.w);
+  lo.x = pack_bf16(a.x - __uint_as_float(hi.x << 16), b.x - __uint_as_float(hi.x & 0xffff0000u));
+  lo.y = pack_bf16(a.y - __uint_as_float(hi.y << 16), b.y - __uint_as_float(hi.y & 0xffff0000u));
+  lo.z = pack_bf16(a.z - __uint_as_float(hi.z << 16), b.z - __uint_as_float(hi.z & 0xffff0000u));
+  lo.w = pack_bf16(a.w - __uint_as_float(hi.w << 16), b.w - __uint_as_float(hi.w & 0xffff0000u));
+}
+
+__global__ __launch_bounds__(kThreads, 3) void gemm_tn_bf3_kernel(const GemmBatch batch) {
+  const GemmP& p = batch.g[0];
+  constexpr int TM = 2, TN = 2;
+  constexpr int PAIRS = BK / 2;                 // row pairs per tile
+  constexpr int HALF = PAIRS * LD;              // dwords per half (hi or lo) of one operand's tile image
+  constexpr int SLOT = 2 * HALF;
+  __shared__ __align__(16) unsigned smem[3 * SLOT * 2];
+  unsigned* const As = smem;
+  unsigned* const Bs = smem + 3 * SLOT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lm = lane & 31, h = lane >> 5;
+
+  const int tiles_n = p.N / BN, nwg = (p.M / BM) * tiles_n;
+  const int split = p.split_k;
+  const int total = nwg * (int)gridDim.z;
+  const int q = xcd_swizzle((int)(blockIdx.x + gridDim.x * blockIdx.z), total);
+  const int per_slice = nwg * p.taps;
+  const int zs = q / per_slice, ztap = (q % per_slice) / nwg, bid = q % nwg;
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int chunk = (p.K + split - 1) / split;
+  chunk = (chunk + BK - 1) / BK * BK;
+  const int k_begin = zs * chunk, k_end = min(p.K, k_begin + chunk);
+  if (k_begin >= k_end) return;
+  const int n_iter = (k_end - k_begin) / BK;
+  const int shift = p.T > 0 ? p.shift0 + ztap * p.shift_step : 0;
+
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B) + (long)shift * p.ldb, 0, 0x7FFFFFF0, 0x00020000);
+  constexpr unsigned kOob = 0x80000000u;
+  auto buf_load = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, int soff) {
+    const auto r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, soff, 0);
+    const unsigned x = r[0], y = r[1], z = r[2], w = r[3];
+    return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
+  };
+
+  // staging: thread (j = tid >> 5, c = 4 (tid & 31)) holds columns c .. c + 3 of rows 2j and 2j + 1 of a tile
+  const int kpair = tid >> 5, kcol = (tid & 31) * 4;
+  const unsigned a_goff = (unsigned)(2 * kpair * p.lda + m0 + kcol) * 4u, b_goff = (unsigned)(2 * kpair * p.ldb + n0 + kcol) * 4u;
+  const unsigned a_row = (unsigned)p.lda * 4u, b_row = (unsigned)p.ldb * 4u;
+  const unsigned st_off = (unsigned)(kpair * LD + kcol);
+  float4 ra[2], rb[2];
+  const int a_step = BK * p.lda * 4, b_step = BK * p.ldb * 4;
+  int a_s = k_begin * p.lda * 4, b_s = k_begin * p.ldb * 4;
+  const int a_last = (k_end - BK) * p.lda * 4;
+  int ts = (p.T > 0 ? k_begin % p.T : 0) + shift;
+  const unsigned Tu = p.T > 0 ? (unsigned)p.T : 0x7FFFFFFFu;
+  auto load_tile = [&]() {
+    ra[0] = buf_load(rsrc_a, a_goff, a_s);
+    ra[1] = buf_load(rsrc_a, a_goff + a_row, a_s);
+    rb[0] = buf_load(rsrc_b, (unsigned)(ts + 2 * kpair) < Tu ? b_goff : kOob, b_s);
+    rb[1] = buf_load(rsrc_b, (unsigned)(ts + 2 * kpair + 1) < Tu ? b_goff + b_row : kOob, b_s);
+    if (a_s < a_last) {
+      a_s += a_step;
+      b_s += b_step;
+      if (p.T > 0) { ts += BK; if (ts >= p.T + shift) ts -= p.T; }
+    }
+  };
+  auto store_tile = [&](int slot) {
+    uint4 hi, lo;
+    split_pair4(ra[0], ra[1], hi, lo);
+    *reinterpret_cast<uint4*>(As + slot * SLOT + st_off) = hi;
+    *reinterpret_cast<uint4*>(As + slot * SLOT + HALF + st_off) = lo;
+    split_pair4(rb[0], rb[1], hi, lo);
+    *reinterpret_cast<uint4*>(Bs + slot * SLOT + st_off) = hi;
+    *reinterpret_cast<uint4*>(Bs + slot * SLOT + HALF + st_off) = lo;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_tile();
+  store_tile(0);
+  load_tile();
+  __syncthreads();
+
+  const unsigned* a_rd = As + 4 * h * LD + wm * 64 + lm;
+  const unsigned* b_rd = Bs + 4 * h * LD + wn * 64 + lm;
+  // One tile: fragments read, the registers holding tile it+1 to the next ring slot and reloaded with tile it+2,
+  // twelve matrix instructions, barrier.  (Ring slot (it+1) % 3 was last read as tile it-2.)
+  auto tile_step = [&](auto slot_c) {
+    constexpr int S = decltype(slot_c)::value, NS = (S + 1) % 3;
+    uint4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const unsigned* r = a_rd + S * SLOT + pl * HALF + i * 32;
+        fa[pl][i] = make_uint4(r[0], r[LD], r[2 * LD], r[3 * LD]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned* r = b_rd + S * SLOT + pl * HALF + j * 32;
+        fb[pl][j] = make_uint4(r[0], r[LD], r[2 * LD], r[3 * LD]);
+      }
+    }
+    store_tile(NS);
+    load_tile();
+#pragma unroll
+    for (int term = 0; term < 3; ++term) {
+      const int qa = term == 0 ? 1 : 0, qb = term == 1 ? 1 : 0;        // lo.hi, hi.lo, hi.hi
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[qa][i]), __builtin_bit_cast(bf16x8, fb[qb][j]),
+                                                             acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  int it = 0;
+  for (; it + 3 <= n_iter; it += 3) { tile_step(I0{}); tile_step(I1{}); tile_step(I2{}); }
+  if (it < n_iter) {
+    tile_step(I0{});
+    if (it + 1 < n_iter) tile_step(I1{});
+  }
+
+  const EpiArgs e = make_epi_args(p);
+  float* Cz = e.C + (long)ztap * e.tap_stride_c;
+  epilogue_full<BM, BN, true, false>(acc, e, Cz, DropoutP{0.f, 0, nullptr}, m0, n0, tile_m, wave, lane);
+}
+
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace
@@ -208,9 +361,10 @@ int ocean_launch_gemm_tn(const GemmBatch& b, hipStream_t stream) {
   void* tok = nullptr;
   if (ocean_prof_on()) {
     const double bytes = 4.0 * ((double)p.M * p.K + (double)p.N * p.K * p.taps + (double)p.M * p.N * p.taps);
-    ocean_prof_begin("gemm_tn_kernel", 2.0 * p.M * p.N * (double)p.K * p.taps, bytes, stream, &tok);
+    ocean_prof_begin(ocean_split_bf16() ? "gemm_tn_bf3_kernel" : "gemm_tn_kernel", 2.0 * p.M * p.N * (double)p.K * p.taps, bytes, stream, &tok);
   }
-  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(kThreads), 0, stream, g);
+  if (ocean_split_bf16()) hipLaunchKernelGGL(gemm_tn_bf3_kernel, grid, dim3(kThreads), 0, stream, g);
+  else hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(kThreads), 0, stream, g);
   ocean_prof_end(tok, stream);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;

@@ -169,6 +169,8 @@ def _declare_rest(lib) -> None:
     sig("ocean_gnn_layer_output", c_int, POINTER(GnnShape), c_int, POINTER(c_size_t), POINTER(c_int))
     sig("ocean_gnn_edge_kernel_family", c_int, POINTER(GnnShape))
     sig("ocean_prof_enable", c_int, c_int)
+    sig("ocean_set_split_bf16", c_int, c_int)
+    sig("ocean_get_split_bf16", c_int)
     sig("ocean_clear_last_error", c_int)
     sig("ocean_prof_summary", c_int, ctypes.c_char_p, c_size_t)
     sig("ocean_grad_sqnorm", c_int, vp, c_int, vp, vp)
@@ -211,6 +213,19 @@ def check(status: int, what: str) -> None:
     if status >= 1000:
         raise OceanHipError(f"{what}: HIP error {status - 1000}")
     raise OceanHipError(f"{what}: {_STATUS.get(status, 'status ' + str(status))}")
+
+
+def split_bf16() -> bool:
+    """Whether the large convolution products run on split bf16 operands (see set_split_bf16)."""
+    return bool(lib().ocean_get_split_bf16())
+
+
+def set_split_bf16(on: bool) -> bool:
+    """Opt-in arithmetic for the large (full-tile) products of the convolutions and their gradients: every fp32 operand
+    is split into two bf16 values and the product formed by three bf16 matrix instructions with fp32 accumulation -
+    about 16 bits of each product instead of 24, at roughly twice the speed.  Process-wide; returns the previous setting.
+    Recorded HIP graphs are keyed on it, so a learner records a new step after a change."""
+    return bool(lib().ocean_set_split_bf16(1 if on else 0))
 
 
 def dev_ptr(t: Optional[torch.Tensor], name: str = "tensor", dtype=torch.float32) -> c_void_p:

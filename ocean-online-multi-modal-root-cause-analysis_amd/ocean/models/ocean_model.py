@@ -207,7 +207,7 @@ class OCEANModel(nn.Module):
         adj, nf = service_graph.adjacency_matrix, service_graph.node_features
         sentinel = self.prediction_head[0].weight
         key = (tuple(metrics.shape), None if logs is None else tuple(logs.shape), id(service_graph)) + DeviceGraph.tensor_key(adj) + (
-               nf.data_ptr(), nf._version, tuple(nf.shape), sentinel.data_ptr(), str(sentinel.device))
+               nf.data_ptr(), nf._version, tuple(nf.shape), sentinel.data_ptr(), str(sentinel.device), _hip.split_bf16())
         rec = self._graphed_fwd.get(key)
         if rec is None:
             n = self._graph_fwd_seen.pop(key, 0) + 1

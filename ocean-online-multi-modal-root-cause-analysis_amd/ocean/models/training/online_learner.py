@@ -470,7 +470,7 @@ class OnlineLearner:
         key = (tuple(metrics.shape), tuple(logs.shape), tuple(labels.shape), id(service_graph)) + DeviceGraph.tensor_key(adj) + (
                nf.data_ptr(), nf._version, tuple(nf.shape), getattr(self.model, "trainable_version", 0),
                tuple(grp["betas"]), grp["eps"], grp["weight_decay"], self.config.training.gradient_clip_norm,
-               self.model.contrastive_negatives)
+               self.model.contrastive_negatives, _hip.split_bf16())
         step = self._graphed.get(key)
         if step is not None and step.generation != self.optimizer.generation:
             self._drop_recordings()                # the optimizer state was reloaded: every recording is stale

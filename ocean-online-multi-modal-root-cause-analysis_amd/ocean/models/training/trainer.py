@@ -269,7 +269,7 @@ class Trainer:
         key = (tuple(metrics.shape), tuple(logs.shape), tuple(labels.shape), id(sg)) + DeviceGraph.tensor_key(adj) + (
                nf.data_ptr(), nf._version, tuple(nf.shape), getattr(self.model, "trainable_version", 0), tuple(grp["betas"]), grp["eps"],
                grp["weight_decay"], self.config.training.gradient_clip_norm, self.model.contrastive_negatives,
-               lf.prediction_weight, lf.contrastive_weight, lf.consistency_weight, lf.diversity_weight)
+               lf.prediction_weight, lf.contrastive_weight, lf.consistency_weight, lf.diversity_weight, _hip.split_bf16())
         step = self._graphed.get(key)
         if step is not None and step.generation != opt.generation:
             self._graphed.clear()                  # the optimizer state was reloaded: every recording is stale
