@@ -1,24 +1,25 @@
 """Summarise a rocprofv3 --pmc run of tools/bench_gemm.py: matrix-pipe utilisation and wave-state split per GEMM launch.
 
-    python tools/pmc_gemm.py results.db
+    python tools/pmc_gemm.py results.db [kernel-name substring, default gemm_f32_kernel]
 """
 import collections
 import sqlite3
 import sys
 
 db = sqlite3.connect(sys.argv[1])
+PAT = sys.argv[2] if len(sys.argv) > 2 else "gemm_f32_kernel"
 cur = db.cursor()
 d = collections.defaultdict(dict)
 q = ("select dispatch_id, substr(kernel_name,1,110), grid_size, counter_name, sum(value), max(duration) from counters_collection "
-     "where kernel_name like '%gemm_f32_kernel%' group by dispatch_id, counter_name")
+     f"where kernel_name like '%{PAT}%' group by dispatch_id, counter_name")
 for did, name, gs, cn, val, dur in cur.execute(q):
-    d[did]["name"] = name[name.find("gemm_f32_kernel") + 15:][:36]
+    d[did]["name"] = name[name.find(PAT) + (15 if PAT == "gemm_f32_kernel" else 0):][:36]
     d[did]["grid"] = gs
     d[did][cn] = val
     d[did]["dur"] = dur
 seen = set()
 for did, v in sorted(d.items()):
-    key = (v["name"], v["grid"])
+    key = (v["name"], v["grid"]) if PAT == "gemm_f32_kernel" else (v["name"], v["grid"], round(v["dur"] / 20000.0))
     if key in seen:
         continue
     seen.add(key)
