@@ -173,9 +173,10 @@ def main():
     ap.add_argument("--services", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (by default the step is replayed as a HIP graph)")
-    ap.add_argument("--split-bf16", action="store_true",
+    ap.add_argument("--split-bf16", nargs="?", const="all", default=None, choices=["all", "backward"],
                     help="secondary, labelled line (never the headline): the large convolution products on fp32 operands split into "
-                         "two bf16 values, three bf16 matrix instructions per product, fp32 accumulation")
+                         "two bf16 values, three bf16 matrix instructions per product, fp32 accumulation; 'backward' keeps the "
+                         "forward pass fp32")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -236,7 +237,7 @@ def main():
     model.contrastive_negatives = "in_batch"
     learner = OnlineLearner(model, cfg)
     if args.split_bf16:
-        ocean.set_split_bf16(True)
+        ocean.set_split_bf16(args.split_bf16)
     if use_dist:
         from ocean.parallel import DataParallel, HostStagedTransport
         transport = HostStagedTransport() if rehearse else None
@@ -298,7 +299,7 @@ def main():
             "value": world * B * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if args.weak else "strong",
-            "vs_baseline": None, "dtype": "bf16x3 (fp32 operands split hi + lo, fp32 accumulate)" if args.split_bf16 else "f32",
+            "vs_baseline": None, "dtype": ("bf16x3 (fp32 operands split hi + lo, fp32 accumulate)" + (" in the backward pass, f32 forward" if args.split_bf16 == "backward" else "")) if args.split_bf16 else "f32",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2] (C3): {N} services (ER graph, in-degree 8), global batch {world * B} "
                                    f"({B} per GPU), seq_len {T}, "
@@ -307,8 +308,10 @@ def main():
                        "global_batch": world * B, "batch_per_gpu": B, "seq_len": T, "services": N,
                        "parallelism": f"dp{world}" + (" (rehearsal: all ranks on one GPU, gloo)" if rehearse else ""),
                        "launch": "hip-graph replay" + (" (collectives inside the graph)" if use_dist else "") if graphed else "eager",
-                       "arithmetic": ("SECONDARY LINE, not the headline: large convolution products as hi.hi + hi.lo + lo.hi of bf16 halves "
-                                      "(about 16 bits per product), everything else fp32; roofline counts the bf16 instructions issued"
+                       "arithmetic": ("SECONDARY LINE, not the headline: large convolution products"
+                                      + (" of the backward pass" if args.split_bf16 == "backward" else "")
+                                      + " as hi.hi + hi.lo + lo.hi of bf16 halves (about 16 bits per product), everything else fp32; "
+                                      "roofline counts the bf16 instructions issued"
                                       if args.split_bf16 else "fp32 throughout")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": recorded_traffic(dom["kernel"]) if (B, T, N, world, use_dist, args.split_bf16) == (1024, 128, 256, 1, False, False) else None,

@@ -36,11 +36,13 @@ int ocean_abi_version(void);
 
 /* Opt-in arithmetic for the large (full-tile) products of the convolutions: each fp32 operand is split into two bf16
  * values (x = hi + lo) on its way into LDS and the product formed as hi.hi + hi.lo + lo.hi by three bf16 matrix
- * instructions with fp32 accumulation - about 16 bits of each product instead of 24, at several times the fp32
- * matrix rate.  Off by default (also: environment OCEAN_GEMM_SPLIT_BF16=1 at load time); process-wide; returns the
- * previous setting.  Set it before a step is recorded into a HIP graph - a recording keeps the kernels it was made
- * with.  No counterpart in the reference (torch fp32 on its device's default matmul path). */
-int ocean_set_split_bf16(int on);
+ * instructions with fp32 accumulation - about 16 bits of each product instead of 24, at 2-2.5 times the fp32 rate.
+ * mode 0 (default): fp32 products.  mode 1: every large product.  mode 2: only the products launched by the backward
+ * drivers (ocean_dcnn_bwd*, ocean_gnn_bwd): the forward pass, and with it the sign of every ReLU input, stays fp32.
+ * Process-wide (also: environment OCEAN_GEMM_SPLIT_BF16=1|2 at load time); returns the previous mode, or -1 for a mode
+ * outside 0..2.  Set it before a step is recorded into a HIP graph - a recording keeps the kernels it
+ * was made with.  No counterpart in the reference (torch fp32 on its device's default matmul path). */
+int ocean_set_split_bf16(int mode);
 int ocean_get_split_bf16(void);
 
 /* ------------------------------------------------------------------ GEMM

@@ -5,22 +5,33 @@
 #include <cstdlib>
 
 namespace {
+// 0: fp32 products; 1: split-bf16 products in every large GEMM; 2: only inside the backward drivers
 std::atomic<int>& split_flag() {
-  static std::atomic<int> f{getenv("OCEAN_GEMM_SPLIT_BF16") != nullptr && atoi(getenv("OCEAN_GEMM_SPLIT_BF16")) != 0 ? 1 : 0};
+  static std::atomic<int> f{[] {
+    const char* e = getenv("OCEAN_GEMM_SPLIT_BF16");
+    const int v = e ? atoi(e) : 0;
+    return v == 1 || v == 2 ? v : 0;
+  }()};
   return f;
 }
+thread_local int backward_depth = 0;
 }  // namespace
-bool ocean_split_bf16() { return split_flag().load(std::memory_order_relaxed) != 0; }
+OceanBackwardScope::OceanBackwardScope() { ++backward_depth; }
+OceanBackwardScope::~OceanBackwardScope() { --backward_depth; }
+bool ocean_split_bf16() {
+  const int m = split_flag().load(std::memory_order_relaxed);
+  return m == 1 || (m == 2 && backward_depth > 0);
+}
 
 extern "C" {
 
 int ocean_abi_version(void) { return 1; }
 
-int ocean_set_split_bf16(int on) {
-  const int prev = split_flag().exchange(on ? 1 : 0, std::memory_order_relaxed);
-  return prev;
+int ocean_set_split_bf16(int mode) {
+  if (mode < 0 || mode > 2) return -1;
+  return split_flag().exchange(mode, std::memory_order_relaxed);
 }
-int ocean_get_split_bf16(void) { return ocean_split_bf16() ? 1 : 0; }
+int ocean_get_split_bf16(void) { return split_flag().load(std::memory_order_relaxed); }
 
 int ocean_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                    int a_kmajor, int b_kn, const float* bias, const float* R, int ldr, int relu, void* stream) {

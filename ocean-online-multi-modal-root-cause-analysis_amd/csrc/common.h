@@ -147,9 +147,11 @@ int ocean_launch_gemm_skinny(const GemmBatch& b, hipStream_t stream);
 // when both are few-tile work, else ocean_launch_gemm_batch(w) then ocean_launch_gemm_batch(d)
 int ocean_launch_gemm_pair(const GemmP* w, int nw, const GemmP* d, int nd, hipStream_t stream);
 
-// whether the large products run as three bf16 matrix instructions on split operands instead of one fp32 one
-// (opt-in: ocean_set_split_bf16 / OCEAN_GEMM_SPLIT_BF16=1; api.hip)
+// whether the large product about to be launched by this thread runs as three bf16 matrix instructions on split
+// operands instead of one fp32 one (opt-in: ocean_set_split_bf16 / OCEAN_GEMM_SPLIT_BF16; api.hip)
 bool ocean_split_bf16();
+// alive for the duration of a backward driver call: mode 2 splits only the products launched under one
+struct OceanBackwardScope { OceanBackwardScope(); ~OceanBackwardScope(); };
 
 // the kernel for large products of two k-contiguous operands with full tiles (gemm_nt.hip), likewise
 bool ocean_gemm_nt_applies(const GemmBatch& b);

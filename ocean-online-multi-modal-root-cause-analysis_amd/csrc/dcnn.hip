@@ -824,12 +824,14 @@ extern "C" {
 
 int ocean_dcnn_bwd(const ocean_dcnn_shape* s, const float* x, float* const* params, float* wf, float* wb, size_t wb_floats,
                    const float* dout, float* const* grads, float* dx, int phase_lo, int phase_hi, void* stream) {
+  const OceanBackwardScope scope;
   return dcnn_bwd_impl(s, x, params, wf, wb, wb_floats, dout, grads, dx, phase_lo, phase_hi, 3, stream);
 }
 
 int ocean_dcnn_bwd_part(const ocean_dcnn_shape* s, const float* x, float* const* params, float* wf, float* wb, size_t wb_floats,
                         const float* dout, float* const* grads, float* dx, int phase, int part, void* stream) {
   if (part != 0 && part != 1) return OCEAN_ERR_BAD_SHAPE;
+  const OceanBackwardScope scope;
   return dcnn_bwd_impl(s, x, params, wf, wb, wb_floats, dout, grads, dx, phase, phase + 1, part == 0 ? 1 : 2, stream);
 }
 

@@ -1380,6 +1380,7 @@ int ocean_gnn_fwd(const ocean_gnn_shape* s, const float* node_features, const in
 
 int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const int* const* graph, float* const* params,
                   float* wf, float* wb, size_t wb_floats, const float* dout, float* const* grads, void* stream) {
+  const OceanBackwardScope scope;
   GnnPlan pl;
   OCEAN_TRY(make_plan(s, &pl));
   if (!node_features || !graph || !params || !wf || !wb || !dout || !grads) return OCEAN_ERR_NULL;

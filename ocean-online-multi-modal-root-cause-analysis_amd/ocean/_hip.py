@@ -215,17 +215,31 @@ def check(status: int, what: str) -> None:
     raise OceanHipError(f"{what}: {_STATUS.get(status, 'status ' + str(status))}")
 
 
-def split_bf16() -> bool:
-    """Whether the large convolution products run on split bf16 operands (see set_split_bf16)."""
-    return bool(lib().ocean_get_split_bf16())
+_SPLIT_MODES = {False: 0, True: 1, 0: 0, 1: 1, 2: 2, "off": 0, "all": 1, "backward": 2}
 
 
-def set_split_bf16(on: bool) -> bool:
+def split_bf16() -> int:
+    """The arithmetic of the large convolution products: 0 fp32, 1 split bf16 everywhere, 2 split bf16 in the backward
+    pass only (see set_split_bf16)."""
+    return int(lib().ocean_get_split_bf16())
+
+
+def set_split_bf16(mode) -> int:
     """Opt-in arithmetic for the large (full-tile) products of the convolutions and their gradients: every fp32 operand
     is split into two bf16 values and the product formed by three bf16 matrix instructions with fp32 accumulation -
-    about 16 bits of each product instead of 24, at roughly twice the speed.  Process-wide; returns the previous setting.
-    Recorded HIP graphs are keyed on it, so a learner records a new step after a change."""
-    return bool(lib().ocean_set_split_bf16(1 if on else 0))
+    about 16 bits of each product instead of 24, at 2-2.5 times the speed.  `mode`: False / "off"; True / "all" (forward
+    and backward); "backward" (the two gradient products only: the forward pass, and so every ReLU's sign, stays fp32).
+    Process-wide; returns the previous mode (0, 1 or 2).  Recorded HIP graphs are keyed on it, so a learner records a new
+    step after a change."""
+    if mode not in _SPLIT_MODES:
+        raise ValueError(f"split-bf16 mode must be one of False, True, 'off', 'all', 'backward', 0, 1, 2 (got {mode!r})")
+    return check_mode(lib().ocean_set_split_bf16(_SPLIT_MODES[mode]))
+
+
+def check_mode(rc: int) -> int:
+    if rc < 0:
+        raise OceanHipError(f"ocean_set_split_bf16 status {rc}")
+    return int(rc)
 
 
 def dev_ptr(t: Optional[torch.Tensor], name: str = "tensor", dtype=torch.float32) -> c_void_p:

@@ -13,12 +13,12 @@ from oracle import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def split_mode():
+@pytest.fixture(params=["all", "backward"])
+def split_mode(request):
     import ocean
-    prev = ocean.set_split_bf16(True)
+    prev = ocean.set_split_bf16(request.param)
     try:
-        yield
+        yield request.param
     finally:
         ocean.set_split_bf16(prev)
 
@@ -63,15 +63,20 @@ def _conv_products(T=128, B=256, C=256, d=4):
 
 def test_switch_returns_previous_setting_and_changes_the_products():
     import ocean
-    assert ocean.split_bf16() is False              # off unless asked for
+    assert ocean.split_bf16() == 0                  # off unless asked for
     e_fwd, e_wg = _conv_products()
     prev = ocean.set_split_bf16(True)
     try:
-        assert prev is False and ocean.split_bf16() is True
+        assert prev == 0 and ocean.split_bf16() == 1
         s_fwd, s_wg = _conv_products()
+        assert ocean.set_split_bf16("backward") == 1 and ocean.split_bf16() == 2
+        b_fwd, b_wg = _conv_products()               # called outside a backward driver: fp32 products
+        with pytest.raises(ValueError):
+            ocean.set_split_bf16("sometimes")
     finally:
-        assert ocean.set_split_bf16(False) is True
-    assert ocean.split_bf16() is False
+        assert ocean.set_split_bf16(False) == 2
+    assert ocean.split_bf16() == 0
+    assert b_fwd < 2e-6 and b_wg < 2e-6, (b_fwd, b_wg)
     assert e_fwd < 2e-6 and e_wg < 2e-6, (e_fwd, e_wg)
     # three bf16 products carry about 16 bits: worse than fp32, far better than one bf16 product (4e-3)
     assert e_fwd < s_fwd < 3e-5, (e_fwd, s_fwd)
@@ -79,8 +84,8 @@ def test_switch_returns_previous_setting_and_changes_the_products():
 
 
 def test_headline_shape_step_in_split_mode_stays_inside_the_fp32_bounds(split_mode):
-    """Batch 1024 x 128 timesteps x 256 services (every convolution product on the split kernels), dropout 0, against the
-    CPU oracle: the same bounds as the fp32 path's full-size test."""
+    """Batch 1024 x 128 timesteps x 256 services (every convolution product on the split kernels, or those of the backward
+    pass only), dropout 0, against the CPU oracle: the same bounds as the fp32 path's full-size test."""
     import ocean
     from ocean.data import ServiceGraph
     from ocean.optim import FusedAdam
