@@ -314,7 +314,7 @@ def main():
                                       "roofline counts the bf16 instructions issued"
                                       if args.split_bf16 else "fp32 throughout")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": recorded_traffic(dom["kernel"]) if (B, T, N, world, use_dist, args.split_bf16) == (1024, 128, 256, 1, False, False) else None,
+                         "frac": achieved / peak, "traffic": recorded_traffic(dom["kernel"]) if (B, T, N, world, use_dist, bool(args.split_bf16)) == (1024, 128, 256, 1, False, False) else None,
                          "traffic_unit": "bytes/launch (HBM-side fetch+write, separate rocprofv3 --pmc passes of the default command; "
                                          "null unless recorded with this very library and script, and for any other shape)",
                          "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "kernel": dom["kernel"],
