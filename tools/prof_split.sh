@@ -17,4 +17,5 @@ timeout -k 10 300 python $R/bench.py --split-bf16 backward --no-cpu-baseline > $
 (cd $R && OCEAN_GEMM_SPLIT_BF16=1 timeout -k 10 900 python -u -m pytest tests -m gpu -q --timeout 300 --timeout-method thread -p no:cacheprovider --deselect tests/test_gpu_split_bf16.py 2>&1 | grep -E "^FAILED|passed|failed" > $OUT/split_all_gpu_tests.txt || true)
 OCEAN_GEMM_SPLIT_BF16=1 timeout -k 10 200 python -u $R/tools/bench_gemm.py > /tmp/prof_split/gemm.txt 2> /tmp/prof_split/gemm.err || { tail -5 /tmp/prof_split/gemm.err; exit 1; }
 sed -n 1,22p /tmp/prof_split/gemm.txt > $OUT/split_gemm_microbench.txt
+(cd $R && timeout -k 10 300 python -u tools/split_training_check.py 200 2>/dev/null > $OUT/split_training.txt)
 echo collected

@@ -21,6 +21,6 @@ cp $F/streaming.jsonl profiles/${P}_streaming.jsonl
 cp $F/metrics.jsonl profiles/${P}_metrics.jsonl
 cp $F/gat_instruction_mix.txt profiles/${P}_gat_instruction_mix.txt
 cp $F/gat_traffic.txt profiles/${P}_gat_traffic.txt
-for f in bench_b128.json bench_dp.jsonl gemm_ksweep.txt split_bench_n1.json split_bench_b128.json split_kernel_stats_eager.txt split_bench_under_rocprof_eager.json split_gemm_microbench.txt split_backward_bench_n1.json split_backward_gpu_tests.txt split_all_gpu_tests.txt; do
+for f in bench_b128.json bench_dp.jsonl gemm_ksweep.txt split_bench_n1.json split_bench_b128.json split_kernel_stats_eager.txt split_bench_under_rocprof_eager.json split_gemm_microbench.txt split_backward_bench_n1.json split_backward_gpu_tests.txt split_all_gpu_tests.txt split_training.txt; do
   if [ -f $F/$f ]; then cp $F/$f profiles/${P}_$f; fi
 done
