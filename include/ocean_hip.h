@@ -254,7 +254,7 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* temporal, const f
  * ContrastiveLearningModule.forward calls it per modality, :217-221): y = normalize(W1 . dropout(relu(W0 x + b0)) + b1),
  * two layers with ReLU (the reference's default); normalize == 0 leaves the last Linear's output as it is.
  * params / grads: {0.weight [hidden,in], 0.bias, 3.weight [out,hidden], 3.bias}; gradients are ADDED to grads
- * (NULL entries are skipped together with their data gradient's layer only when both are NULL); dx may be NULL. */
+ * (a NULL entry skips that gradient alone); dx may be NULL (the input's gradient is then not formed). */
 typedef struct {
   int B, in_dim, hidden, out_dim;
   int training, normalize;
