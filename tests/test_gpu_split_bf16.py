@@ -170,3 +170,21 @@ def test_a_learner_records_a_new_step_when_the_mode_changes():
         ocean.set_split_bf16(prev)
     learner.process_tensors(x, sg, l, y)
     assert len(learner._graphed) == 2                # back on the first recording
+
+
+def test_large_row_dcnn_gradients_keep_their_bounds_with_the_backward_products_split():
+    """The two random-shape DilatedCNN cases at >= 16 384 rows whose element-wise gradient bound (5 % of the largest
+    element) the all-products setting exceeds - more ReLU inputs change sign in a 16-bit forward pass - run unchanged,
+    bounds included, when only the backward products are split."""
+    import importlib.util
+    import pathlib
+    import ocean
+    spec = importlib.util.spec_from_file_location("_dcnn_parity_tests", pathlib.Path(__file__).with_name("test_gpu_dcnn.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    prev = ocean.set_split_bf16("backward")
+    try:
+        mod.test_against_oracle_random(256, 128, [64, 128], [3, 32], 3)
+        mod.test_against_oracle_random(512, 64, [64, 128], [2, 5], 3)
+    finally:
+        ocean.set_split_bf16(prev)
