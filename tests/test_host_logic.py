@@ -270,3 +270,32 @@ def test_model_copies_do_not_carry_device_caches():
         assert clone.use_hip_graph is True and clone._graphed_fwd == {} and clone._graph_fwd_seen == {}
         for (k, a), (_, b) in zip(m.state_dict().items(), clone.state_dict().items()):
             assert torch.equal(a, b), k
+
+
+def test_new_entry_points_validate_their_arguments_before_touching_the_gpu():
+    """Shape, workspace and pointer checks of the projection-head entry points and the arithmetic switch run on the
+    host: they answer with a status (and launch nothing) on a machine without a GPU too."""
+    import ctypes
+    from ocean import _hip
+    L = _hip.lib()
+    sh = _hip.ProjShape()
+    sh.B, sh.in_dim, sh.hidden, sh.out_dim, sh.training, sh.normalize, sh.dropout = 4, 8, 8, 6, 0, 1, 0.0
+    need = L.ocean_projection_head_fwd_workspace(ctypes.byref(sh))
+    assert need >= 4 * 8 + 4 * 6 + 4 and L.ocean_projection_head_bwd_workspace(ctypes.byref(sh)) >= 4 * 6 + 4 * 8
+    null = ctypes.c_void_p(0)
+    table = (ctypes.c_void_p * 4)()
+    one = ctypes.c_void_p(16)                       # never dereferenced: every call below is refused first
+    assert L.ocean_projection_head_fwd(ctypes.byref(sh), null, table, one, need, one, null) != 0          # no input
+    assert L.ocean_projection_head_fwd(ctypes.byref(sh), one, table, one, need - 1, one, null) != 0      # workspace too small
+    bad = _hip.ProjShape()
+    bad.B, bad.in_dim, bad.hidden, bad.out_dim, bad.dropout = 4, 0, 8, 6, 0.0
+    assert L.ocean_projection_head_fwd_workspace(ctypes.byref(bad)) == 0
+    bad.in_dim, bad.dropout = 8, 1.0
+    assert L.ocean_projection_head_fwd_workspace(ctypes.byref(bad)) == 0
+    L.ocean_clear_last_error()
+    prev = L.ocean_get_split_bf16()
+    assert L.ocean_set_split_bf16(3) == -1 and L.ocean_set_split_bf16(-2) == -1 and L.ocean_get_split_bf16() == prev
+    assert L.ocean_set_split_bf16(2) == prev and L.ocean_get_split_bf16() == 2
+    assert L.ocean_set_split_bf16(prev) == 2
+    with pytest.raises(ValueError):
+        _hip.set_split_bf16("half")
