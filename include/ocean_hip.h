@@ -223,6 +223,48 @@ int ocean_mfa_bwd(const ocean_mfa_shape* s, const float* temporal, const float* 
                   float* const* grads, float* d_temporal, float* d_spatial, float* d_logs /* each may be NULL */,
                   void* stream);
 
+/* ------------------------------------------------------------------ MultiHeadAttention on its own
+ * Replaces MultiHeadAttention.forward and ScaledDotProductAttention.forward (multi_factor_attention.py:108-148,
+ * 34-65) for callers outside MultiFactorAttention (whose length-1 sequences ocean_mfa_* handles): query / key / value
+ * [B, L, D] of equal length, mask [B, L, L] (0 = masked: score -1e9) or NULL, dropout on the attention weights and on
+ * the output.  attn [B, heads, L, L] holds the weights as the reference returns them (after dropout).  L <= 1024.
+ * params / grads: {w_q.weight, w_q.bias, w_k.weight, w_k.bias, w_v.weight, w_v.bias, w_o.weight, w_o.bias}; gradients are
+ * ADDED to grads (NULL entries skipped); d_out or d_attn may be NULL (not both); dq / dk / dv may be NULL. */
+typedef struct {
+  int B, L, D, heads;
+  int training;
+  float dropout;
+  uint64_t seed;
+  const uint64_t* seed_epoch;
+} ocean_mha_shape;
+size_t ocean_mha_fwd_workspace(const ocean_mha_shape* s);
+size_t ocean_mha_bwd_workspace(const ocean_mha_shape* s);
+int ocean_mha_fwd(const ocean_mha_shape* s, const float* query, const float* key, const float* value, const float* mask,
+                  float* const* params, float* ws, size_t ws_floats, float* out /* [B,L,D] */,
+                  float* attn /* [B,heads,L,L] */, void* stream);
+int ocean_mha_bwd(const ocean_mha_shape* s, const float* query, const float* key, const float* value, float* const* params,
+                  const float* ws_fwd, const float* attn, const float* d_out, const float* d_attn, float* ws_bwd,
+                  size_t ws_bwd_floats, float* const* grads, float* dq, float* dk, float* dv, void* stream);
+
+/* The rest of CrossModalAttention.forward after its MultiHeadAttention (multi_factor_attention.py:205-215):
+ * y1 = LayerNorm(query + attended); out = LayerNorm(y1 + Dropout(Linear(Dropout(ReLU(Linear(y1)))))), rows = B * L.
+ * params / grads: {layer_norm.weight, .bias, feed_forward.0.weight [F,D], .0.bias, feed_forward.3.weight [D,F], .3.bias,
+ * ff_layer_norm.weight, .bias}; gradients are ADDED to grads; d_sum receives the gradient of (query + attended),
+ * which is the gradient of each of the two.  D <= 1024. */
+typedef struct {
+  int rows, D, F;
+  int training;
+  float dropout, eps;
+  uint64_t seed;
+  const uint64_t* seed_epoch;
+} ocean_xattn_tail_shape;
+size_t ocean_xattn_tail_fwd_workspace(const ocean_xattn_tail_shape* s);
+size_t ocean_xattn_tail_bwd_workspace(const ocean_xattn_tail_shape* s);
+int ocean_xattn_tail_fwd(const ocean_xattn_tail_shape* s, const float* query, const float* attended, float* const* params,
+                         float* ws, size_t ws_floats, float* out, void* stream);
+int ocean_xattn_tail_bwd(const ocean_xattn_tail_shape* s, float* const* params, const float* ws_fwd, const float* d_out,
+                         float* ws_bwd, size_t ws_bwd_floats, float* const* grads, float* d_sum, void* stream);
+
 /* ------------------------------------------------------------------ GraphFusionModule
  * Replaces GraphFusionModule.forward with fusion_strategy='attention'
  * (ocean/models/components/graph_fusion.py:388-473) including

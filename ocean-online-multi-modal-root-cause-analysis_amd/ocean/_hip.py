@@ -101,6 +101,16 @@ class ProjShape(ctypes.Structure):
                 ("normalize", c_int), ("dropout", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
 
 
+class MhaShape(ctypes.Structure):
+    _fields_ = [("B", c_int), ("L", c_int), ("D", c_int), ("heads", c_int), ("training", c_int), ("dropout", c_float),
+                ("seed", c_uint64), ("seed_epoch", c_void_p)]
+
+
+class XattnTailShape(ctypes.Structure):
+    _fields_ = [("rows", c_int), ("D", c_int), ("F", c_int), ("training", c_int), ("dropout", c_float), ("eps", c_float),
+                ("seed", c_uint64), ("seed_epoch", c_void_p)]
+
+
 class AdamChunk(ctypes.Structure):
     _fields_ = [("param", c_uint64), ("grad", c_uint64), ("exp_avg", c_uint64), ("exp_avg_sq", c_uint64),
                 ("n", ctypes.c_int64)]
@@ -143,6 +153,16 @@ def _declare_rest(lib) -> None:
     sig("ocean_projection_head_bwd_workspace", c_size_t, pp)
     sig("ocean_projection_head_fwd", c_int, pp, vp, tp, vp, c_size_t, vp, vp)
     sig("ocean_projection_head_bwd", c_int, pp, vp, tp, vp, vp, vp, vp, c_size_t, tp, vp, vp)
+    ap_ = POINTER(MhaShape)
+    sig("ocean_mha_fwd_workspace", c_size_t, ap_)
+    sig("ocean_mha_bwd_workspace", c_size_t, ap_)
+    sig("ocean_mha_fwd", c_int, ap_, vp, vp, vp, vp, tp, vp, c_size_t, vp, vp, vp)
+    sig("ocean_mha_bwd", c_int, ap_, vp, vp, vp, tp, vp, vp, vp, vp, vp, c_size_t, tp, vp, vp, vp, vp)
+    xp = POINTER(XattnTailShape)
+    sig("ocean_xattn_tail_fwd_workspace", c_size_t, xp)
+    sig("ocean_xattn_tail_bwd_workspace", c_size_t, xp)
+    sig("ocean_xattn_tail_fwd", c_int, xp, vp, vp, tp, vp, c_size_t, vp, vp)
+    sig("ocean_xattn_tail_bwd", c_int, xp, tp, vp, vp, vp, c_size_t, tp, vp, vp)
     sig("ocean_bce_fwd", c_int, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_bce_bwd", c_int, vp, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_conv_gemm_f32", c_int, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_int, vp)

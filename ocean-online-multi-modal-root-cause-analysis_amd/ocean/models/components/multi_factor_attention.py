@@ -26,7 +26,61 @@ class ScaledDotProductAttention(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, *a, **k):
-        raise NotImplementedError("container only: MultiFactorAttention drives the HIP kernels")
+        raise NotImplementedError("runs inside MultiHeadAttention's HIP driver (scores, softmax, dropout and context "
+                                  "are one kernel there); call MultiHeadAttention")
+
+
+class _MhaFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, module, *params):
+        L = _hip.lib()
+        sh = _hip.MhaShape()
+        sh.B, sh.L, sh.D, sh.heads = q.shape[0], q.shape[1], q.shape[2], module.num_heads
+        sh.training = int(module.training)
+        sh.dropout = float(module.dropout.p) if module.training else 0.0
+        sh.seed = _hip.new_seed(sh.dropout)
+        sh.seed_epoch = _hip.seed_epoch(q.device).data_ptr() if sh.dropout > 0 else None
+        ctx.set_materialize_grads(False)
+        nws = L.ocean_mha_fwd_workspace(ctypes.byref(sh))
+        if nws == 0:
+            raise _hip.OceanHipError(f"MultiHeadAttention: unsupported shape {tuple(q.shape)} with {module.num_heads} heads "
+                                     "(sequence length at most 1024)")
+        ws = torch.empty(nws, device=q.device, dtype=torch.float32)
+        out = torch.empty_like(q)
+        attn = torch.empty(sh.B, sh.heads, sh.L, sh.L, device=q.device, dtype=torch.float32)
+        _hip.check(L.ocean_mha_fwd(ctypes.byref(sh), _hip.dev_ptr(q, "query"), _hip.dev_ptr(k, "key"), _hip.dev_ptr(v, "value"),
+                                   _hip.dev_ptr(mask, "mask"), _hip.ptr_table(params, "attention param"), _hip.dev_ptr(ws),
+                                   ws.numel(), _hip.dev_ptr(out), _hip.dev_ptr(attn), _hip.stream()), "ocean_mha_fwd")
+        ctx.sh = sh
+        ctx.save_for_backward(q, k, v, ws, attn, *[p for p in params if p is not None])
+        ctx.has = [p is not None for p in params]
+        return out, attn
+
+    @staticmethod
+    def backward(ctx, d_out, d_attn):
+        n_in = 5 + len(ctx.has)
+        if d_out is None and d_attn is None:
+            return (None,) * n_in
+        L = _hip.lib()
+        q, k, v, ws, attn, *live = ctx.saved_tensors
+        it = iter(live)
+        params = [next(it) if h else None for h in ctx.has]
+        sh = ctx.sh
+        wb = torch.empty(L.ocean_mha_bwd_workspace(ctypes.byref(sh)), device=q.device, dtype=torch.float32)
+        present = [p for p in params if p is not None]
+        got = iter(_hip.zero_grads_like(present))
+        grads = [next(got) if p is not None else None for p in params]
+        dq = torch.empty_like(q) if ctx.needs_input_grad[0] else None
+        dk = torch.empty_like(k) if ctx.needs_input_grad[1] else None
+        dv = torch.empty_like(v) if ctx.needs_input_grad[2] else None
+        c = lambda g: None if g is None else g.contiguous().float()
+        _hip.check(L.ocean_mha_bwd(ctypes.byref(sh), _hip.dev_ptr(q), _hip.dev_ptr(k), _hip.dev_ptr(v),
+                                   _hip.ptr_table(params, "attention param"), _hip.dev_ptr(ws), _hip.dev_ptr(attn),
+                                   _hip.dev_ptr(c(d_out)), _hip.dev_ptr(c(d_attn)), _hip.dev_ptr(wb), wb.numel(),
+                                   _hip.ptr_table(grads, "attention grad"), _hip.dev_ptr(dq), _hip.dev_ptr(dk), _hip.dev_ptr(dv),
+                                   _hip.stream()), "ocean_mha_bwd")
+        return (dq, dk, dv, None, None) + tuple(g if (g is not None and ctx.needs_input_grad[5 + i]) else None
+                                                 for i, g in enumerate(grads))
 
 
 class MultiHeadAttention(nn.Module):
@@ -45,8 +99,26 @@ class MultiHeadAttention(nn.Module):
         self.attention = ScaledDotProductAttention(self.d_k, dropout)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("container only: MultiFactorAttention drives the HIP kernels")
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, mask=None):
+        """The module on its own (multi_factor_attention.py:108-148): (output [B, L, D], attention weights [B, heads, L, L]
+        after dropout).  As in the reference, key and value are viewed with the query's sequence length, so the three
+        must agree in shape; mask [B, L, L] (or broadcastable to it), 0 = masked."""
+        if query.dim() != 3 or query.shape[2] != self.d_model:
+            raise RuntimeError(f"expected query of shape [batch, seq_len, {self.d_model}], got {tuple(query.shape)}")
+        if key.shape != query.shape or value.shape != query.shape:
+            raise RuntimeError(f"shape '[{query.shape[0]}, {query.shape[1]}, {self.num_heads}, {self.d_k}]' is invalid for input "
+                               f"of size {key.numel() if key.shape != query.shape else value.numel()}")
+        if self.attention.dropout.p != self.dropout.p:
+            raise NotImplementedError("one dropout probability for the attention weights and the output")
+        B, L, _ = query.shape
+        m = None
+        if mask is not None:
+            m = torch.as_tensor(mask, device=query.device)
+            m = (m != 0).to(torch.float32).expand(B, L, L).contiguous()
+        q, k, v = (x.contiguous().float() for x in (query, key, value))
+        params = [self.w_q.weight, self.w_q.bias, self.w_k.weight, self.w_k.bias, self.w_v.weight, self.w_v.bias,
+                  self.w_o.weight, self.w_o.bias]
+        return _MhaFunction.apply(q, k, v, m, self, *params)
 
 
 class CrossModalAttention(nn.Module):
@@ -61,8 +133,60 @@ class CrossModalAttention(nn.Module):
                                           nn.Linear(d_model * 4, d_model), nn.Dropout(dropout))
         self.ff_layer_norm = nn.LayerNorm(d_model)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("not on the OCEAN model path")
+    def forward(self, query_modality: torch.Tensor, key_value_modality: torch.Tensor, mask=None):
+        """The block on its own (multi_factor_attention.py:190-215): attention of the query modality over the other one,
+        residual + LayerNorm, feed-forward, residual + LayerNorm.  Returns (output, attention weights)."""
+        attended, weights = self.multihead_attention(query_modality, key_value_modality, key_value_modality, mask)
+        ff = self.feed_forward
+        drops = {m.p for m in ff if isinstance(m, nn.Dropout)}
+        if len(drops) > 1 or self.layer_norm.eps != self.ff_layer_norm.eps:
+            raise NotImplementedError("one dropout probability and one epsilon per block")
+        params = [self.layer_norm.weight, self.layer_norm.bias, ff[0].weight, ff[0].bias, ff[3].weight, ff[3].bias,
+                  self.ff_layer_norm.weight, self.ff_layer_norm.bias]
+        q = query_modality.contiguous().float()
+        out = _XattnTailFunction.apply(q, attended, self, float(next(iter(drops))) if drops else 0.0, *params)
+        return out, weights
+
+
+class _XattnTailFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, attended, module, p, *params):
+        L = _hip.lib()
+        sh = _hip.XattnTailShape()
+        sh.rows, sh.D, sh.F = q.shape[0] * q.shape[1], q.shape[2], params[2].shape[0]
+        sh.training, sh.eps = int(module.training), float(module.layer_norm.eps)
+        sh.dropout = p if module.training else 0.0
+        sh.seed = _hip.new_seed(sh.dropout)
+        sh.seed_epoch = _hip.seed_epoch(q.device).data_ptr() if sh.dropout > 0 else None
+        ctx.set_materialize_grads(False)
+        nws = L.ocean_xattn_tail_fwd_workspace(ctypes.byref(sh))
+        if nws == 0:
+            raise _hip.OceanHipError(f"CrossModalAttention: unsupported width {sh.D} (at most 1024)")
+        ws = torch.empty(nws, device=q.device, dtype=torch.float32)
+        out = torch.empty_like(q)
+        _hip.check(L.ocean_xattn_tail_fwd(ctypes.byref(sh), _hip.dev_ptr(q, "query"), _hip.dev_ptr(attended.contiguous(), "attended"),
+                                          _hip.ptr_table(params, "block param"), _hip.dev_ptr(ws), ws.numel(), _hip.dev_ptr(out),
+                                          _hip.stream()), "ocean_xattn_tail_fwd")
+        ctx.sh = sh
+        ctx.save_for_backward(ws, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        if d_out is None:
+            return (None,) * (4 + 8)
+        L = _hip.lib()
+        ws, *params = ctx.saved_tensors
+        sh = ctx.sh
+        wb = torch.empty(L.ocean_xattn_tail_bwd_workspace(ctypes.byref(sh)), device=ws.device, dtype=torch.float32)
+        grads = _hip.zero_grads_like(params)
+        d_sum = torch.empty_like(d_out, memory_format=torch.contiguous_format)
+        _hip.check(L.ocean_xattn_tail_bwd(ctypes.byref(sh), _hip.ptr_table(params, "block param"), _hip.dev_ptr(ws),
+                                          _hip.dev_ptr(d_out.contiguous().float()), _hip.dev_ptr(wb), wb.numel(),
+                                          _hip.ptr_table(grads, "block grad"), _hip.dev_ptr(d_sum), _hip.stream()),
+                   "ocean_xattn_tail_bwd")
+        return (d_sum if ctx.needs_input_grad[0] else None, d_sum if ctx.needs_input_grad[1] else None, None, None) + tuple(
+            g if ctx.needs_input_grad[4 + i] else None for i, g in enumerate(grads))
 
 
 class _MfaFunction(torch.autograd.Function):
