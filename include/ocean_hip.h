@@ -223,6 +223,29 @@ int ocean_mfa_bwd(const ocean_mfa_shape* s, const float* temporal, const float* 
                   float* const* grads, float* d_temporal, float* d_spatial, float* d_logs /* each may be NULL */,
                   void* stream);
 
+/* ------------------------------------------------------------------ DilatedConvBlock on its own
+ * Replaces DilatedConvBlock.forward (dilated_cnn.py:76-99) for callers outside DilatedCNN (whose blocks ocean_dcnn_*
+ * runs): out = Dropout(ReLU(BatchNorm(Conv1d(x)))) + residual, residual = x when Cin == Cout (res_conv = 0), else
+ * BatchNorm(Conv1d 1x1 (x)) (res_conv = 1).  x, out, dx: channels-last [B*T, C] rows (sample, time).  Odd kernel sizes
+ * (symmetric padding (k-1)*dilation/2 keeps the length).  Training mode needs B*T >= 2 and updates the running statistics.
+ * params / grads: {conv.weight [Cout,Cin,k], batch_norm.weight, .bias, .running_mean, .running_var,
+ * residual_conv.weight [Cout,Cin,1], residual_bn.weight, .bias, .running_mean, .running_var} (the last five only with
+ * res_conv); gradients are ADDED to grads (entries 3, 4, 8, 9 - the buffers - are ignored; NULL entries skipped). */
+typedef struct {
+  int B, T, Cin, Cout, kernel, dilation;
+  int training, res_conv;
+  float dropout, eps, momentum;
+  uint64_t seed;
+  const uint64_t* seed_epoch;
+} ocean_convblock_shape;
+size_t ocean_convblock_fwd_workspace(const ocean_convblock_shape* s);
+size_t ocean_convblock_bwd_workspace(const ocean_convblock_shape* s);
+int ocean_convblock_fwd(const ocean_convblock_shape* s, const float* x, float* const* params, float* ws, size_t ws_floats,
+                        float* out, void* stream);
+int ocean_convblock_bwd(const ocean_convblock_shape* s, const float* x, float* const* params, const float* ws_fwd,
+                        const float* dy, float* ws_bwd, size_t ws_bwd_floats, float* const* grads, float* dx /* or NULL */,
+                        void* stream);
+
 /* ------------------------------------------------------------------ MultiHeadAttention on its own
  * Replaces MultiHeadAttention.forward and ScaledDotProductAttention.forward (multi_factor_attention.py:108-148,
  * 34-65) for callers outside MultiFactorAttention (whose length-1 sequences ocean_mfa_* handles): query / key / value

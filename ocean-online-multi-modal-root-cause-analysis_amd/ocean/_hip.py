@@ -111,6 +111,12 @@ class XattnTailShape(ctypes.Structure):
                 ("seed", c_uint64), ("seed_epoch", c_void_p)]
 
 
+class ConvBlockShape(ctypes.Structure):
+    _fields_ = [("B", c_int), ("T", c_int), ("Cin", c_int), ("Cout", c_int), ("kernel", c_int), ("dilation", c_int),
+                ("training", c_int), ("res_conv", c_int), ("dropout", c_float), ("eps", c_float), ("momentum", c_float),
+                ("seed", c_uint64), ("seed_epoch", c_void_p)]
+
+
 class AdamChunk(ctypes.Structure):
     _fields_ = [("param", c_uint64), ("grad", c_uint64), ("exp_avg", c_uint64), ("exp_avg_sq", c_uint64),
                 ("n", ctypes.c_int64)]
@@ -163,6 +169,11 @@ def _declare_rest(lib) -> None:
     sig("ocean_xattn_tail_bwd_workspace", c_size_t, xp)
     sig("ocean_xattn_tail_fwd", c_int, xp, vp, vp, tp, vp, c_size_t, vp, vp)
     sig("ocean_xattn_tail_bwd", c_int, xp, tp, vp, vp, vp, c_size_t, tp, vp, vp)
+    cp_ = POINTER(ConvBlockShape)
+    sig("ocean_convblock_fwd_workspace", c_size_t, cp_)
+    sig("ocean_convblock_bwd_workspace", c_size_t, cp_)
+    sig("ocean_convblock_fwd", c_int, cp_, vp, tp, vp, c_size_t, vp, vp)
+    sig("ocean_convblock_bwd", c_int, cp_, vp, tp, vp, vp, vp, c_size_t, tp, vp, vp)
     sig("ocean_bce_fwd", c_int, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_bce_bwd", c_int, vp, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_conv_gemm_f32", c_int, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_int, vp)

@@ -44,8 +44,74 @@ class DilatedConvBlock(nn.Module):
             self.residual_bn = nn.BatchNorm1d(out_channels)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError(
-            "DilatedConvBlock is executed by DilatedCNN's fused HIP driver; call the parent DilatedCNN")
+        """The block on its own (dilated_cnn.py:76-99): x [batch, in_channels, seq_len] -> [batch, out_channels, seq_len].
+        DilatedCNN runs its blocks inside its fused driver instead."""
+        if self.activation_name != "relu" or self.kernel_size % 2 == 0:
+            raise NotImplementedError("the HIP path implements relu activation and odd kernel sizes")
+        if x.dim() != 3 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"expected input [batch, {self.in_channels}, seq_len], got {tuple(x.shape)}")
+        B, _, T = x.shape
+        bns = [self.batch_norm] + ([] if self.use_residual else [self.residual_bn])
+        if self.training:
+            if B * T < 2:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {torch.Size([B, self.out_channels, T])}")
+            if any(bn.momentum is None or not bn.track_running_stats for bn in bns):
+                raise NotImplementedError("BatchNorm with running statistics and a fixed momentum")
+        params = [self.conv.weight, self.batch_norm.weight, self.batch_norm.bias, self.batch_norm.running_mean,
+                  self.batch_norm.running_var]
+        if not self.use_residual:
+            params += [self.residual_conv.weight, self.residual_bn.weight, self.residual_bn.bias, self.residual_bn.running_mean,
+                       self.residual_bn.running_var]
+        rows = x.permute(0, 2, 1).contiguous().float().view(B * T, self.in_channels)           # channels last
+        out = _ConvBlockFunction.apply(rows, self, B, T, *params)
+        if self.training:
+            for bn in bns:
+                bn.num_batches_tracked += 1
+        return out.view(B, T, self.out_channels).permute(0, 2, 1).contiguous()
+
+
+class _ConvBlockFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, module, B, T, *params):
+        L = _hip.lib()
+        sh = _hip.ConvBlockShape()
+        sh.B, sh.T, sh.Cin, sh.Cout = B, T, module.in_channels, module.out_channels
+        sh.kernel, sh.dilation = module.kernel_size, module.dilation
+        sh.training, sh.res_conv = int(module.training), int(not module.use_residual)
+        sh.dropout = float(module.dropout.p) if module.training else 0.0
+        sh.eps, sh.momentum = float(module.batch_norm.eps), float(module.batch_norm.momentum or 0.0)
+        sh.seed = _hip.new_seed(sh.dropout)
+        sh.seed_epoch = _hip.seed_epoch(rows.device).data_ptr() if sh.dropout > 0 else None
+        ctx.set_materialize_grads(False)
+        nws = L.ocean_convblock_fwd_workspace(ctypes.byref(sh))
+        if nws == 0:
+            raise _hip.OceanHipError(f"DilatedConvBlock: unsupported shape (kernel size {module.kernel_size})")
+        ws = torch.empty(nws, device=rows.device, dtype=torch.float32)
+        out = torch.empty(B * T, sh.Cout, device=rows.device, dtype=torch.float32)
+        _hip.check(L.ocean_convblock_fwd(ctypes.byref(sh), _hip.dev_ptr(rows, "x"), _hip.ptr_table(params, "block param"),
+                                         _hip.dev_ptr(ws), ws.numel(), _hip.dev_ptr(out), _hip.stream()), "ocean_convblock_fwd")
+        ctx.sh = sh
+        ctx.save_for_backward(rows, ws, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        n_in = 4 + (10 if ctx.sh.res_conv else 5)
+        if dy is None:
+            return (None,) * n_in
+        L = _hip.lib()
+        rows, ws, *params = ctx.saved_tensors
+        sh = ctx.sh
+        wb = torch.empty(L.ocean_convblock_bwd_workspace(ctypes.byref(sh)), device=rows.device, dtype=torch.float32)
+        learn = [i for i in range(len(params)) if i % 5 not in (3, 4)]
+        got = iter(_hip.zero_grads_like([params[i] for i in learn]))
+        grads = [next(got) if i in learn else None for i in range(len(params))]
+        dx = torch.empty_like(rows) if ctx.needs_input_grad[0] else None
+        _hip.check(L.ocean_convblock_bwd(ctypes.byref(sh), _hip.dev_ptr(rows), _hip.ptr_table(params, "block param"), _hip.dev_ptr(ws),
+                                         _hip.dev_ptr(dy.contiguous().float()), _hip.dev_ptr(wb), wb.numel(),
+                                         _hip.ptr_table(grads, "block grad"), _hip.dev_ptr(dx), _hip.stream()), "ocean_convblock_bwd")
+        return (dx, None, None, None) + tuple(g if (g is not None and ctx.needs_input_grad[4 + i]) else None
+                                              for i, g in enumerate(grads))
 
 
 class _DcnnFunction(torch.autograd.Function):
