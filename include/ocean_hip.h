@@ -252,11 +252,15 @@ int ocean_convblock_bwd(const ocean_convblock_shape* s, const float* x, float* c
  * [B, L, D] of equal length, mask [B, L, L] (0 = masked: score -1e9) or NULL, dropout on the attention weights and on
  * the output.  attn [B, heads, L, L] holds the weights as the reference returns them (after dropout).  L <= 1024.
  * params / grads: {w_q.weight, w_q.bias, w_k.weight, w_k.bias, w_v.weight, w_v.bias, w_o.weight, w_o.bias}; gradients are
- * ADDED to grads (NULL entries skipped); d_out or d_attn may be NULL (not both); dq / dk / dv may be NULL. */
+ * ADDED to grads (NULL entries skipped); d_out or d_attn may be NULL (not both); dq / dk / dv may be NULL.
+ * project == 0 is ScaledDotProductAttention.forward alone (:34-65): query / key / value are the heads' vectors laid out
+ * [B, L, heads * d], no parameters (params / grads may be NULL), `out` is the attended values, dq / dk / dv are required. */
 typedef struct {
   int B, L, D, heads;
   int training;
+  int project;              /* 1: the four linear layers around the attention; 0: the attention alone */
   float dropout;
+  float scale;              /* factor on the scores; 0: 1/sqrt(D/heads) */
   uint64_t seed;
   const uint64_t* seed_epoch;
 } ocean_mha_shape;

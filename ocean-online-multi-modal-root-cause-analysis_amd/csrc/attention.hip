@@ -166,16 +166,24 @@ int ocean_mha_fwd(const ocean_mha_shape* s, const float* query, const float* key
                   float* const* P_, float* ws, size_t ws_floats, float* out, float* attn, void* stream) {
   MhaPlan pl;
   OCEAN_TRY(mha_plan(s, &pl));
-  if (!query || !key || !value || !P_ || !ws || !out || !attn) return OCEAN_ERR_NULL;
+  if (!query || !key || !value || !ws || !out || !attn || (s->project && !P_)) return OCEAN_ERR_NULL;
   if (ws_floats < pl.fwd_total) return OCEAN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int R = s->B * s->L, D = s->D;
+  const float scale = s->scale > 0.f ? s->scale : 1.0f / sqrtf((float)(D / s->heads));
+  const long rows = (long)s->B * s->heads * s->L;
+  if (!s->project) {
+    // the attention alone (ScaledDotProductAttention.forward): the inputs are the heads' queries / keys / values
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st, query, key,
+                       value, mask, ws + pl.P, attn, out, s->B, s->heads, s->L, D, scale, mha_site(s, 0));
+    OCEAN_LAUNCH_CHECK();
+    return OCEAN_OK;
+  }
   OCEAN_TRY(linear_fwd(query, D, P_[0], P_[1], ws + pl.Q, D, R, D, D, 0, st));
   OCEAN_TRY(linear_fwd(key, D, P_[2], P_[3], ws + pl.K, D, R, D, D, 0, st));
   OCEAN_TRY(linear_fwd(value, D, P_[4], P_[5], ws + pl.V, D, R, D, D, 0, st));
-  const long rows = (long)s->B * s->heads * s->L;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st, ws + pl.Q, ws + pl.K,
-                     ws + pl.V, mask, ws + pl.P, attn, ws + pl.ctx, s->B, s->heads, s->L, D, 1.0f / sqrtf((float)(D / s->heads)), mha_site(s, 0));
+                     ws + pl.V, mask, ws + pl.P, attn, ws + pl.ctx, s->B, s->heads, s->L, D, scale, mha_site(s, 0));
   OCEAN_LAUNCH_CHECK();
   const DropoutP d1 = mha_site(s, 1);
   Epi e; e.drop = &d1;
@@ -187,12 +195,26 @@ int ocean_mha_bwd(const ocean_mha_shape* s, const float* query, const float* key
                   float* const* G_, float* dq, float* dk, float* dv, void* stream) {
   MhaPlan pl;
   OCEAN_TRY(mha_plan(s, &pl));
-  if (!query || !key || !value || !P_ || !wf || !attn || !wb || !G_) return OCEAN_ERR_NULL;
+  if (!query || !key || !value || !wf || !attn || !wb || (s->project && (!P_ || !G_))) return OCEAN_ERR_NULL;
   if (!d_out && !d_attn) return OCEAN_ERR_NULL;
   if (wb_floats < pl.bwd_total) return OCEAN_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int R = s->B * s->L, D = s->D;
   const size_t RD = (size_t)R * D;
+  const float scale = s->scale > 0.f ? s->scale : 1.0f / sqrtf((float)(D / s->heads));
+  const float keep = (s->training && s->dropout > 0.f) ? 1.0f / (1.0f - s->dropout) : 1.0f;
+  const long nrows = (long)s->B * s->heads * s->L;
+  if (!s->project) {
+    if (!dq || !dk || !dv) return OCEAN_ERR_NULL;
+    const float* g = d_out;
+    if (!g) { OCEAN_TRY(zero_f32(wb + pl.dctx, RD, st)); g = wb + pl.dctx; }
+    OCEAN_TRY(zero_f32(dk, RD, st));
+    OCEAN_TRY(zero_f32(dv, RD, st));
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((nrows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st, query, key,
+                       value, wf + pl.P, attn, g, d_attn, dq, dk, dv, s->B, s->heads, s->L, D, scale, keep);
+    OCEAN_LAUNCH_CHECK();
+    return OCEAN_OK;
+  }
   if (d_out) {
     // out = dropout(ctx Wo^T + bo): the mask goes onto a copy of the incoming gradient
     const float* g = d_out;
@@ -209,11 +231,9 @@ int ocean_mha_bwd(const ocean_mha_shape* s, const float* query, const float* key
     OCEAN_TRY(zero_f32(wb + pl.dctx, RD, st));
   }
   OCEAN_TRY(zero_f32(wb + pl.dK, 2 * al4(RD), st));        // dK and dV are neighbours in the plan
-  const float keep_scale = (s->training && s->dropout > 0.f) ? 1.0f / (1.0f - s->dropout) : 1.0f;
-  const long rows = (long)s->B * s->heads * s->L;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((rows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st, wf + pl.Q, wf + pl.K,
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((nrows + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(64 * kWavesPerBlock), 0, st, wf + pl.Q, wf + pl.K,
                      wf + pl.V, wf + pl.P, attn, wb + pl.dctx, d_attn, wb + pl.dQ, wb + pl.dK, wb + pl.dV, s->B, s->heads, s->L, D,
-                     1.0f / sqrtf((float)(D / s->heads)), keep_scale);
+                     scale, keep);
   OCEAN_LAUNCH_CHECK();
   const float* x[3] = {query, key, value};
   const float* g3[3] = {wb + pl.dQ, wb + pl.dK, wb + pl.dV};

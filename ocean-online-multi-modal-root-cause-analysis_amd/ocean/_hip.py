@@ -102,8 +102,8 @@ class ProjShape(ctypes.Structure):
 
 
 class MhaShape(ctypes.Structure):
-    _fields_ = [("B", c_int), ("L", c_int), ("D", c_int), ("heads", c_int), ("training", c_int), ("dropout", c_float),
-                ("seed", c_uint64), ("seed_epoch", c_void_p)]
+    _fields_ = [("B", c_int), ("L", c_int), ("D", c_int), ("heads", c_int), ("training", c_int), ("project", c_int),
+                ("dropout", c_float), ("scale", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
 
 
 class XattnTailShape(ctypes.Structure):

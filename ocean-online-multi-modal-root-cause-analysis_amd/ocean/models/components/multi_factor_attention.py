@@ -25,17 +25,43 @@ class ScaledDotProductAttention(nn.Module):
         self.d_model = d_model
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("runs inside MultiHeadAttention's HIP driver (scores, softmax, dropout and context "
-                                  "are one kernel there); call MultiHeadAttention")
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, mask=None):
+        """The attention alone (multi_factor_attention.py:34-65): softmax(Q K^T / sqrt(d_model)) V with dropout on the
+        weights, for [batch, seq_len, d] or [batch, heads, seq_len, d] inputs; mask broadcastable to the scores,
+        0 = masked.  Returns (attended values, attention weights) in the inputs' layout."""
+        if query.dim() not in (3, 4) or key.shape != query.shape or value.shape != query.shape:
+            raise RuntimeError(f"query, key and value of one shape [batch, (heads,) seq_len, d] expected, got "
+                               f"{tuple(query.shape)}, {tuple(key.shape)}, {tuple(value.shape)}")
+        four = query.dim() == 4
+        B, H = query.shape[0], (query.shape[1] if four else 1)
+        L, d = query.shape[-2], query.shape[-1]
+        rows = lambda x: (x.permute(0, 2, 1, 3) if four else x).contiguous().float().view(B, L, H * d)
+        m = None
+        if mask is not None:
+            m = (torch.as_tensor(mask, device=query.device) != 0).to(torch.float32)
+            if m.dim() == 4:
+                if m.shape[1] != 1 and H > 1 and not bool((m == m[:, :1]).all()):
+                    raise NotImplementedError("one mask for all heads of a sample")
+                m = m[:, 0]
+            m = m.expand(B, L, L).contiguous()
+        out, w = _MhaFunction.apply(rows(query), rows(key), rows(value), m, self, H, 1.0 / (self.d_model ** 0.5))
+        if four:
+            return out.view(B, L, H, d).permute(0, 2, 1, 3).contiguous(), w
+        return out, w[:, 0]
 
 
 class _MhaFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, mask, module, *params):
+        # params: the eight tensors of MultiHeadAttention, or (heads, scale) for the attention alone
         L = _hip.lib()
         sh = _hip.MhaShape()
-        sh.B, sh.L, sh.D, sh.heads = q.shape[0], q.shape[1], q.shape[2], module.num_heads
+        project = len(params) == 8
+        sh.B, sh.L, sh.D = q.shape[0], q.shape[1], q.shape[2]
+        sh.heads, sh.scale = (module.num_heads, 0.0) if project else (int(params[0]), float(params[1]))
+        sh.project = int(project)
+        if not project:
+            params = ()
         sh.training = int(module.training)
         sh.dropout = float(module.dropout.p) if module.training else 0.0
         sh.seed = _hip.new_seed(sh.dropout)
@@ -49,7 +75,8 @@ class _MhaFunction(torch.autograd.Function):
         out = torch.empty_like(q)
         attn = torch.empty(sh.B, sh.heads, sh.L, sh.L, device=q.device, dtype=torch.float32)
         _hip.check(L.ocean_mha_fwd(ctypes.byref(sh), _hip.dev_ptr(q, "query"), _hip.dev_ptr(k, "key"), _hip.dev_ptr(v, "value"),
-                                   _hip.dev_ptr(mask, "mask"), _hip.ptr_table(params, "attention param"), _hip.dev_ptr(ws),
+                                   _hip.dev_ptr(mask, "mask"), _hip.ptr_table(params, "attention param") if project else None,
+                                   _hip.dev_ptr(ws),
                                    ws.numel(), _hip.dev_ptr(out), _hip.dev_ptr(attn), _hip.stream()), "ocean_mha_fwd")
         ctx.sh = sh
         ctx.save_for_backward(q, k, v, ws, attn, *[p for p in params if p is not None])
@@ -58,7 +85,8 @@ class _MhaFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out, d_attn):
-        n_in = 5 + len(ctx.has)
+        project = bool(ctx.sh.project)
+        n_in = 5 + (len(ctx.has) if project else 2)
         if d_out is None and d_attn is None:
             return (None,) * n_in
         L = _hip.lib()
@@ -68,17 +96,19 @@ class _MhaFunction(torch.autograd.Function):
         sh = ctx.sh
         wb = torch.empty(L.ocean_mha_bwd_workspace(ctypes.byref(sh)), device=q.device, dtype=torch.float32)
         present = [p for p in params if p is not None]
-        got = iter(_hip.zero_grads_like(present))
+        got = iter(_hip.zero_grads_like(present) if present else [])
         grads = [next(got) if p is not None else None for p in params]
-        dq = torch.empty_like(q) if ctx.needs_input_grad[0] else None
-        dk = torch.empty_like(k) if ctx.needs_input_grad[1] else None
-        dv = torch.empty_like(v) if ctx.needs_input_grad[2] else None
+        dq = torch.empty_like(q) if (ctx.needs_input_grad[0] or not project) else None
+        dk = torch.empty_like(k) if (ctx.needs_input_grad[1] or not project) else None
+        dv = torch.empty_like(v) if (ctx.needs_input_grad[2] or not project) else None
         c = lambda g: None if g is None else g.contiguous().float()
         _hip.check(L.ocean_mha_bwd(ctypes.byref(sh), _hip.dev_ptr(q), _hip.dev_ptr(k), _hip.dev_ptr(v),
-                                   _hip.ptr_table(params, "attention param"), _hip.dev_ptr(ws), _hip.dev_ptr(attn),
-                                   _hip.dev_ptr(c(d_out)), _hip.dev_ptr(c(d_attn)), _hip.dev_ptr(wb), wb.numel(),
-                                   _hip.ptr_table(grads, "attention grad"), _hip.dev_ptr(dq), _hip.dev_ptr(dk), _hip.dev_ptr(dv),
-                                   _hip.stream()), "ocean_mha_bwd")
+                                   _hip.ptr_table(params, "attention param") if project else None, _hip.dev_ptr(ws),
+                                   _hip.dev_ptr(attn), _hip.dev_ptr(c(d_out)), _hip.dev_ptr(c(d_attn)), _hip.dev_ptr(wb), wb.numel(),
+                                   _hip.ptr_table(grads, "attention grad") if project else None, _hip.dev_ptr(dq), _hip.dev_ptr(dk),
+                                   _hip.dev_ptr(dv), _hip.stream()), "ocean_mha_bwd")
+        if not project:
+            return (dq, dk, dv, None, None, None, None)
         return (dq, dk, dv, None, None) + tuple(g if (g is not None and ctx.needs_input_grad[5 + i]) else None
                                                  for i, g in enumerate(grads))
 

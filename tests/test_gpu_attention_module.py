@@ -168,3 +168,35 @@ def test_cross_modal_attention_trains_with_dropout():
     out.square().mean().backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
     assert bool(torch.isfinite(x.grad).all()) and float(x.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("shape,masked", [((3, 7, 16), False), ((2, 4, 9, 8), True), ((1, 1, 70, 32), False), ((2, 5, 24), True)])
+@pytest.mark.parametrize("training", [False, True])
+def test_scaled_dot_product_attention_alone(shape, masked, training):
+    """ScaledDotProductAttention.forward (multi_factor_attention.py:34-65) on [B, L, d] and [B, H, L, d] inputs; the
+    scale is 1/sqrt(d_model) of the constructor, whatever the inputs' last dimension."""
+    from ocean.models.components import ScaledDotProductAttention
+    torch.manual_seed(sum(shape))
+    d_model = 11
+    m = ScaledDotProductAttention(d_model, dropout=0.0 if training else 0.2).cuda().train(training)
+    q, k, v = (torch.randn(*shape) for _ in range(3))
+    L = shape[-2]
+    mask = None
+    if masked:
+        mask = (torch.rand(shape[0], *((1,) if len(shape) == 4 else ()), L, L) > 0.3).long()
+        mask[..., torch.arange(L), torch.arange(L)] = 1
+    qr, kr, vr = (x.clone().requires_grad_(True) for x in (q, k, v))
+    scores = qr @ kr.transpose(-2, -1) / math.sqrt(d_model)
+    if mask is not None:
+        scores = scores.masked_fill(mask == 0, -1e9)
+    w_r = torch.softmax(scores, dim=-1)
+    o_r = w_r @ vr
+    wo, ww = torch.randn_like(o_r), torch.randn_like(w_r)
+    ((o_r * wo).sum() + (w_r * ww).sum()).backward()
+    qg, kg, vg = (x.cuda().requires_grad_(True) for x in (q, k, v))
+    o, w = m(qg, kg, vg, None if mask is None else mask.cuda())
+    close(o, o_r, 1e-5, "attended values")
+    close(w, w_r, 1e-5, "weights")
+    ((o * wo.cuda()).sum() + (w * ww.cuda()).sum()).backward()
+    for name, a, b in (("dq", qg, qr), ("dk", kg, kr), ("dv", vg, vr)):
+        close(a.grad, b.grad, 1e-3, name)
