@@ -299,3 +299,31 @@ def test_new_entry_points_validate_their_arguments_before_touching_the_gpu():
     assert L.ocean_set_split_bf16(prev) == 2
     with pytest.raises(ValueError):
         _hip.set_split_bf16("half")
+
+
+def test_helper_class_entry_points_reject_bad_shapes_on_the_host():
+    """The stand-alone attention and convolution-block drivers size their workspaces (and refuse shapes) without a GPU."""
+    import ctypes
+    from ocean import _hip
+    L = _hip.lib()
+    a = _hip.MhaShape()
+    a.B, a.L, a.D, a.heads, a.project, a.dropout = 2, 5, 32, 4, 1, 0.1
+    assert L.ocean_mha_fwd_workspace(ctypes.byref(a)) >= 4 * 2 * 5 * 32 + 2 * 4 * 25
+    assert L.ocean_mha_bwd_workspace(ctypes.byref(a)) >= 5 * 2 * 5 * 32
+    a.heads = 5                                      # 32 is not a multiple of 5
+    assert L.ocean_mha_fwd_workspace(ctypes.byref(a)) == 0
+    a.heads, a.L = 4, 4096                           # beyond the row-in-LDS limit
+    assert L.ocean_mha_fwd_workspace(ctypes.byref(a)) == 0
+    t = _hip.XattnTailShape()
+    t.rows, t.D, t.F, t.dropout, t.eps = 10, 32, 128, 0.0, 1e-5
+    assert L.ocean_xattn_tail_fwd_workspace(ctypes.byref(t)) >= 10 * (3 * 32 + 128)
+    t.D = 2048
+    assert L.ocean_xattn_tail_fwd_workspace(ctypes.byref(t)) == 0
+    c = _hip.ConvBlockShape()
+    c.B, c.T, c.Cin, c.Cout, c.kernel, c.dilation, c.res_conv, c.dropout = 2, 16, 8, 12, 3, 2, 1, 0.0
+    assert L.ocean_convblock_fwd_workspace(ctypes.byref(c)) >= 12 * 8 * 3 + 2 * 2 * 16 * 12
+    c.res_conv = 0                                   # different widths need the 1x1 residual convolution
+    assert L.ocean_convblock_fwd_workspace(ctypes.byref(c)) == 0
+    c.res_conv, c.kernel = 1, 4                      # even kernels do not keep the sequence length
+    assert L.ocean_convblock_fwd_workspace(ctypes.byref(c)) == 0
+    L.ocean_clear_last_error()
