@@ -79,3 +79,37 @@ def test_dilated_conv_block_dropout_and_errors():
         m(torch.randn(1, 16, 1).cuda())
     with pytest.raises(RuntimeError):
         m(torch.randn(2, 8, 32).cuda())
+
+
+def test_dilated_conv_block_random_shapes():
+    """Seeded random widths (odd ones too), lengths shorter and longer than the receptive field, kernel sizes 1-7,
+    dilations up to 16, both residual forms, training mode (batch statistics, running-statistics update)."""
+    import random
+    from ocean.models.components import DilatedConvBlock
+    rnd = random.Random(11)
+    for case in range(16):
+        cin = rnd.choice([1, 3, 8, 17, 32, 64])
+        cout = cin if rnd.random() < 0.5 else rnd.choice([2, 5, 16, 48, 128])
+        k, d = rnd.choice([1, 3, 5, 7]), rnd.choice([1, 2, 3, 8, 16])
+        B, T = rnd.choice([1, 2, 7]), rnd.choice([2, 3, 16, 40, 128])
+        torch.manual_seed(case)
+        m = DilatedConvBlock(cin, cout, k, d, dropout=0.0)
+        ref = TorchBlock(cin, cout, k, d)
+        ref.load_state_dict(m.state_dict())
+        m = m.cuda().train()
+        x, w = torch.randn(B, cin, T), torch.randn(B, cout, T)
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)
+        (yr * w).sum().backward()
+        xg = x.cuda().requires_grad_(True)
+        y = m(xg)
+        what = f"case {case}: B={B} T={T} {cin}->{cout} k={k} d={d}"
+        close(y, yr, 1e-4, what + " output")
+        (y * w.cuda()).sum().backward()
+        # few rows per channel: BatchNorm's backward is a difference of nearly equal terms there
+        gtol = 1e-2 if B * T <= 4 else 1e-3
+        close(xg.grad, xr.grad, gtol, what + " dx")
+        for name, p in m.named_parameters():
+            close(p.grad, dict(ref.named_parameters())[name].grad, gtol, what + " " + name)
+        for name, b in m.named_buffers():
+            close(b, dict(ref.named_buffers())[name], 1e-5, what + " " + name)
