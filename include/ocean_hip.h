@@ -246,6 +246,28 @@ int ocean_convblock_bwd(const ocean_convblock_shape* s, const float* x, float* c
                         const float* dy, float* ws_bwd, size_t ws_bwd_floats, float* const* grads, float* dx /* or NULL */,
                         void* stream);
 
+/* ------------------------------------------------------------------ one GATConv layer on its own
+ * torch_geometric.nn.GATConv(in, C, heads = H, concat, negative_slope, dropout)(x, edge_index) as the reference's GNN
+ * uses it (graph_neural_network.py:82-90; the published layer: one shared linear map without bias, attention
+ * logits from att_src / att_dst, LeakyReLU, softmax over each target's incoming edges incl. its self loop, dropout on
+ * the coefficients, sum, heads concatenated or averaged, + bias) for callers outside GraphNeuralNetwork (whose layers
+ * ocean_gnn_* runs).  graph[]: the five CSR arrays described at ocean_gnn_shape, E edges incl. self loops.  H*C <= 512.
+ * params / grads: {lin.weight [H*C, in], att_src [H*C], att_dst [H*C], bias [H*C or C] (or NULL)}; gradients are ADDED
+ * to grads (the first three are required); dx [N, in] may be NULL. */
+typedef struct {
+  int N, in_dim, H, C, E;
+  int concat, training;
+  float negative_slope, dropout;
+  uint64_t seed;
+  const uint64_t* seed_epoch;
+} ocean_gatconv_shape;
+size_t ocean_gatconv_fwd_workspace(const ocean_gatconv_shape* s);
+size_t ocean_gatconv_bwd_workspace(const ocean_gatconv_shape* s);
+int ocean_gatconv_fwd(const ocean_gatconv_shape* s, const float* x, const int* const* graph, float* const* params, float* ws,
+                      size_t ws_floats, float* out /* [N, H*C] or [N, C] */, void* stream);
+int ocean_gatconv_bwd(const ocean_gatconv_shape* s, const float* x, const int* const* graph, float* const* params, float* ws_fwd,
+                      const float* dy, float* ws_bwd, size_t ws_bwd_floats, float* const* grads, float* dx, void* stream);
+
 /* ------------------------------------------------------------------ MultiHeadAttention on its own
  * Replaces MultiHeadAttention.forward and ScaledDotProductAttention.forward (multi_factor_attention.py:108-148,
  * 34-65) for callers outside MultiFactorAttention (whose length-1 sequences ocean_mfa_* handles): query / key / value

@@ -1286,6 +1286,60 @@ inline int tile_chunks(const GnnPlan& p) {
   } while (0)
 
 // parameter table: in_w, in_b, then per layer (lin_w, att_src, att_dst, bias), then out_w, out_b
+// y = headmix(agg) + bias: a GATConv layer's own output stage (no activation, residual or feature dropout)
+__global__ void gat_plain_epilogue_kernel(const float* __restrict__ agg, const float* __restrict__ bias, float* __restrict__ y, long rows,
+                                          int H, int C, int concat) {
+  const int od = concat ? H * C : C;
+  const long n = rows * od;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / od;
+    const int c = (int)(idx % od);
+    float v;
+    if (concat) v = agg[row * H * C + c];
+    else {
+      v = 0.f;
+      for (int h = 0; h < H; ++h) v += agg[row * H * C + h * C + c];
+      v /= (float)H;
+    }
+    y[idx] = v + (bias ? bias[c] : 0.f);
+  }
+}
+// dAgg from dy through that stage: dy itself (concat) or dy / H for each head (mean)
+__global__ void gat_plain_bwd_epilogue_kernel(const float* __restrict__ dy, float* __restrict__ dagg, long rows, int H, int C, int concat) {
+  const long n = rows * H * C;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const long row = idx / (H * C);
+    const int hc = (int)(idx % (H * C));
+    dagg[idx] = concat ? dy[idx] : dy[row * C + hc % C] / (float)H;
+  }
+}
+
+struct GatConvPlan { GnnPlan pl; ocean_gnn_shape gs; size_t Z, as_, ad, smax, sden, agg, fwd_total, dagg, Dn, dZ, das, dad, bwd_total; };
+int gatconv_plan(const ocean_gatconv_shape* s, GatConvPlan* p) {
+  if (!s) return OCEAN_ERR_NULL;
+  if (s->N <= 0 || s->in_dim <= 0 || s->H <= 0 || s->C <= 0 || s->E < s->N) return OCEAN_ERR_BAD_SHAPE;
+  if (s->dropout < 0.f || s->dropout >= 1.f) return OCEAN_ERR_BAD_SHAPE;
+  const int D = s->H * s->C;
+  if (D > 64 * 8) return OCEAN_ERR_UNSUPPORTED;               // at most 8 channels per lane
+  GnnPlan& pl = p->pl;
+  pl = GnnPlan{};
+  pl.N = s->N; pl.R = 1; pl.G = s->in_dim; pl.D = D; pl.H = s->H; pl.C = s->C; pl.layers = 1; pl.rows = s->N; pl.pool_n = s->N; pl.P = 1;
+  ocean_gnn_shape& gs = p->gs;
+  gs = ocean_gnn_shape{};
+  gs.N = s->N; gs.R = 1; gs.G = s->in_dim; gs.D = D; gs.H = s->H; gs.layers = 1; gs.E = s->E; gs.pool_n = 0; gs.training = s->training;
+  gs.dropout = s->dropout; gs.negative_slope = s->negative_slope; gs.seed = s->seed; gs.seed_epoch = s->seed_epoch;
+  const size_t rows = (size_t)s->N;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o = al4(o + n); return r; };
+  p->Z = take(rows * D); p->as_ = take(rows * s->H); p->ad = take(rows * s->H); p->smax = take(rows * s->H); p->sden = take(rows * s->H);
+  p->agg = take(rows * D);
+  p->fwd_total = o;
+  o = 0;
+  p->dagg = take(rows * D); p->Dn = take(rows * s->H); p->dZ = take(rows * D); p->das = take(rows * s->H); p->dad = take(rows * s->H);
+  p->bwd_total = o;
+  return OCEAN_OK;
+}
+
 inline int pg_layer(int l, int k) { return 2 + 4 * l + k; }
 inline int pg_out(int layers, int k) { return 2 + 4 * layers + k; }
 
@@ -1498,6 +1552,71 @@ int ocean_gnn_bwd(const ocean_gnn_shape* s, const float* node_features, const in
   }
   OCEAN_TRY(relu_bwd_inplace(dx0, D, wf + pl.x0, D, s->N, D, st));
   OCEAN_TRY(linear_bwd_weight(dx0, D, node_features, s->G, grads[0], s->N, D, s->G, st, grads[1]));   // + bias gradient (column sums of the same operand)
+  return OCEAN_OK;
+}
+
+// ---- one GATConv layer called on its own (the one-node-per-wave kernel family; dropout acts on the attention
+// coefficients only, as in torch_geometric's layer).  params / grads: {lin.weight [H*C, in], att_src [H*C], att_dst [H*C],
+// bias [H*C or C] or NULL}.
+size_t ocean_gatconv_fwd_workspace(const ocean_gatconv_shape* s) { GatConvPlan p; return gatconv_plan(s, &p) == OCEAN_OK ? p.fwd_total : 0; }
+size_t ocean_gatconv_bwd_workspace(const ocean_gatconv_shape* s) { GatConvPlan p; return gatconv_plan(s, &p) == OCEAN_OK ? p.bwd_total : 0; }
+
+int ocean_gatconv_fwd(const ocean_gatconv_shape* s, const float* x, const int* const* graph, float* const* params, float* ws,
+                      size_t ws_floats, float* out, void* stream) {
+  GatConvPlan cp;
+  OCEAN_TRY(gatconv_plan(s, &cp));
+  if (!x || !graph || !params || !ws || !out) return OCEAN_ERR_NULL;
+  if (ws_floats < cp.fwd_total) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const GnnPlan& pl = cp.pl;
+  const int D = pl.D, H = pl.H, C = pl.C;
+  const long rows = pl.rows;
+  GatK g = make_k(&cp.gs, pl, graph, 0);
+  OCEAN_TRY(linear_fwd(x, s->in_dim, params[0], nullptr, ws + cp.Z, D, (int)rows, D, s->in_dim, 0, st));
+  GAT_DISPATCH(gat_scores_kernel, g, ws + cp.Z, params[1], params[2], ws + cp.as_, ws + cp.ad);
+  {
+    const int cpl = cpl_of(pl);
+    const dim3 grid(ceil_div(rows, kWavesPerBlock)), block(256);
+    if (cpl == 1) hipLaunchKernelGGL(gat_aggregate_kernel<1>, grid, block, 0, st, g, ws + cp.Z, ws + cp.as_, ws + cp.ad, ws + cp.agg, ws + cp.smax, ws + cp.sden);
+    else if (cpl == 2) hipLaunchKernelGGL(gat_aggregate_kernel<2>, grid, block, 0, st, g, ws + cp.Z, ws + cp.as_, ws + cp.ad, ws + cp.agg, ws + cp.smax, ws + cp.sden);
+    else if (cpl == 4) hipLaunchKernelGGL(gat_aggregate_kernel<4>, grid, block, 0, st, g, ws + cp.Z, ws + cp.as_, ws + cp.ad, ws + cp.agg, ws + cp.smax, ws + cp.sden);
+    else hipLaunchKernelGGL(gat_aggregate_kernel<8>, grid, block, 0, st, g, ws + cp.Z, ws + cp.as_, ws + cp.ad, ws + cp.agg, ws + cp.smax, ws + cp.sden);
+    OCEAN_LAUNCH_CHECK();
+  }
+  const int od = s->concat ? D : C;
+  hipLaunchKernelGGL(gat_plain_epilogue_kernel, dim3(egrid(rows * od)), dim3(256), 0, st, ws + cp.agg, params[3], out, rows, H, C, s->concat);
+  OCEAN_LAUNCH_CHECK();
+  return OCEAN_OK;
+}
+
+int ocean_gatconv_bwd(const ocean_gatconv_shape* s, const float* x, const int* const* graph, float* const* params, float* wf,
+                      const float* dy, float* wb, size_t wb_floats, float* const* grads, float* dx, void* stream) {
+  GatConvPlan cp;
+  OCEAN_TRY(gatconv_plan(s, &cp));
+  if (!x || !graph || !params || !wf || !dy || !wb || !grads) return OCEAN_ERR_NULL;
+  if (!grads[0] || !grads[1] || !grads[2]) return OCEAN_ERR_NULL;
+  if (wb_floats < cp.bwd_total) return OCEAN_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const GnnPlan& pl = cp.pl;
+  const int D = pl.D, H = pl.H, C = pl.C;
+  const long rows = pl.rows;
+  const int od = s->concat ? D : C;
+  GatK g = make_k(&cp.gs, pl, graph, 0);
+  hipLaunchKernelGGL(gat_plain_bwd_epilogue_kernel, dim3(egrid(rows * D)), dim3(256), 0, st, dy, wb + cp.dagg, rows, H, C, s->concat);
+  OCEAN_LAUNCH_CHECK();
+  if (grads[3]) OCEAN_TRY(colsum_add(dy, od, (int)rows, od, grads[3], st));
+  GAT_DISPATCH(gat_bwd_dot_kernel, g, wb + cp.dagg, wf + cp.agg, wb + cp.Dn);
+  OCEAN_TRY(zero_f32(wb + cp.dad, rows * H, st));
+  GAT_DISPATCH(gat_bwd_source_kernel, g, wf + cp.Z, wf + cp.as_, wf + cp.ad, wf + cp.smax, wf + cp.sden, wb + cp.dagg, wb + cp.Dn, wb + cp.dZ,
+               wb + cp.das, wb + cp.dad);
+  hipLaunchKernelGGL(gat_bwd_att_param_kernel, dim3(ceil_div(D, 64), ceil_div(rows, kAttRows)), dim3(64), 0, st, wf + cp.Z, wb + cp.das,
+                     wb + cp.dad, grads[1], grads[2], rows, H, C);
+  OCEAN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gat_bwd_att_apply_kernel, dim3(egrid(rows * D)), dim3(256), 0, st, wb + cp.dZ, wb + cp.das, wb + cp.dad, params[1],
+                     params[2], rows, H, C);
+  OCEAN_LAUNCH_CHECK();
+  OCEAN_TRY(linear_bwd_weight(wb + cp.dZ, D, x, s->in_dim, grads[0], (int)rows, D, s->in_dim, st));
+  if (dx) OCEAN_TRY(linear_bwd_data(wb + cp.dZ, D, params[0], dx, s->in_dim, (int)rows, D, s->in_dim, 0, st));
   return OCEAN_OK;
 }
 

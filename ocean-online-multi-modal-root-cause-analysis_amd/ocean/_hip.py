@@ -117,6 +117,11 @@ class ConvBlockShape(ctypes.Structure):
                 ("seed", c_uint64), ("seed_epoch", c_void_p)]
 
 
+class GatConvShape(ctypes.Structure):
+    _fields_ = [("N", c_int), ("in_dim", c_int), ("H", c_int), ("C", c_int), ("E", c_int), ("concat", c_int), ("training", c_int),
+                ("negative_slope", c_float), ("dropout", c_float), ("seed", c_uint64), ("seed_epoch", c_void_p)]
+
+
 class AdamChunk(ctypes.Structure):
     _fields_ = [("param", c_uint64), ("grad", c_uint64), ("exp_avg", c_uint64), ("exp_avg_sq", c_uint64),
                 ("n", ctypes.c_int64)]
@@ -174,6 +179,11 @@ def _declare_rest(lib) -> None:
     sig("ocean_convblock_bwd_workspace", c_size_t, cp_)
     sig("ocean_convblock_fwd", c_int, cp_, vp, tp, vp, c_size_t, vp, vp)
     sig("ocean_convblock_bwd", c_int, cp_, vp, tp, vp, vp, vp, c_size_t, tp, vp, vp)
+    gp_ = POINTER(GatConvShape)
+    sig("ocean_gatconv_fwd_workspace", c_size_t, gp_)
+    sig("ocean_gatconv_bwd_workspace", c_size_t, gp_)
+    sig("ocean_gatconv_fwd", c_int, gp_, vp, tp, tp, vp, c_size_t, vp, vp)
+    sig("ocean_gatconv_bwd", c_int, gp_, vp, tp, tp, vp, vp, vp, c_size_t, tp, vp, vp)
     sig("ocean_bce_fwd", c_int, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_bce_bwd", c_int, vp, vp, vp, c_long, c_long, vp, vp)
     sig("ocean_conv_gemm_f32", c_int, vp, c_int, vp, c_int, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_int, vp)

@@ -97,8 +97,63 @@ class GATConv(nn.Module):
             state_dict.pop(prefix + "lin_dst.weight", None)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
-    def forward(self, x, edge_index):
-        raise NotImplementedError("GATConv is executed by GraphNeuralNetwork's fused HIP driver")
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor) -> torch.Tensor:
+        """The layer on its own, as torch_geometric's GATConv(x, edge_index): x [num_nodes, in_channels], edge_index
+        [2, E] (source, target) -> [num_nodes, heads * out_channels] (concat) or [num_nodes, out_channels].
+        GraphNeuralNetwork runs its layers inside its fused driver instead."""
+        if x.dim() != 2 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"expected x of shape [num_nodes, {self.in_channels}], got {tuple(x.shape)}")
+        key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), x.shape[0], str(x.device))
+        cached = getattr(self, "_device_graph", None)
+        if cached is None or cached[0] != key:
+            cached = (key, DeviceGraph.from_edge_index(edge_index, x.shape[0], x.device))
+            self._device_graph = cached
+        params = [self.lin.weight, self.att_src, self.att_dst, self.bias]
+        return _GatConvFunction.apply(x.contiguous().float(), self, cached[1], *params)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_device_graph", None)                 # device-side cache: rebuilt on the next call
+        return state
+
+
+class _GatConvFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module, graph, *params):
+        L = _hip.lib()
+        sh = _hip.GatConvShape()
+        sh.N, sh.in_dim, sh.H, sh.C, sh.E = x.shape[0], x.shape[1], module.heads, module.out_channels, graph.num_edges
+        sh.concat, sh.training = int(module.concat), int(module.training)
+        sh.negative_slope = float(module.negative_slope)
+        sh.dropout = float(module.dropout) if module.training else 0.0
+        sh.seed = _hip.new_seed(sh.dropout)
+        sh.seed_epoch = _hip.seed_epoch(x.device).data_ptr() if sh.dropout > 0 else None
+        ctx.set_materialize_grads(False)
+        nws = L.ocean_gatconv_fwd_workspace(ctypes.byref(sh))
+        if nws == 0:
+            raise _hip.OceanHipError(f"GATConv: unsupported shape (heads * out_channels = {sh.H * sh.C}, at most 512)")
+        ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+        out = torch.empty(sh.N, sh.H * sh.C if module.concat else sh.C, device=x.device, dtype=torch.float32)
+        _hip.check(L.ocean_gatconv_fwd(ctypes.byref(sh), _hip.dev_ptr(x, "x"), graph.table, _hip.ptr_table(params, "GATConv param"),
+                                       _hip.dev_ptr(ws), ws.numel(), _hip.dev_ptr(out), _hip.stream()), "ocean_gatconv_fwd")
+        ctx.sh, ctx.graph = sh, graph
+        ctx.save_for_backward(x, ws, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return (None,) * 7
+        L = _hip.lib()
+        x, ws, *params = ctx.saved_tensors
+        sh = ctx.sh
+        wb = torch.empty(L.ocean_gatconv_bwd_workspace(ctypes.byref(sh)), device=x.device, dtype=torch.float32)
+        grads = _hip.zero_grads_like(params)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        _hip.check(L.ocean_gatconv_bwd(ctypes.byref(sh), _hip.dev_ptr(x), ctx.graph.table, _hip.ptr_table(params, "GATConv param"),
+                                       _hip.dev_ptr(ws), _hip.dev_ptr(dy.contiguous().float()), _hip.dev_ptr(wb), wb.numel(),
+                                       _hip.ptr_table(grads, "GATConv grad"), _hip.dev_ptr(dx), _hip.stream()), "ocean_gatconv_bwd")
+        return (dx, None, None) + tuple(g if ctx.needs_input_grad[3 + i] else None for i, g in enumerate(grads))
 
 
 class _GnnFunction(torch.autograd.Function):
