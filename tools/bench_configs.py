@@ -9,7 +9,9 @@
 
     python tools/bench_configs.py [C1 P T C2 C4 C5]
 
-Prints one JSON line per configuration.  Same synthetic-input recipe as bench.py.
+Prints one JSON line per configuration and launch mode (eager, replayed), and for C2 / C4 one more replayed line with
+the backward products of the large convolutions split into bf16 halves (labelled).  Same synthetic-input recipe as
+bench.py.
 """
 import json
 import os
@@ -81,7 +83,19 @@ def predict(use_graph=True, B=32, N=256, T=128):
             "p50": ts[len(ts) // 2] * 1e3, "p99": ts[int(len(ts) * 0.99)] * 1e3, "launch": "hip-graph replay" if m._graphed_fwd else "eager"}
 
 
-def train_cfg(name, N, S, deg, B, T, steps, use_graph=True):
+def train_cfg(name, N, S, deg, B, T, steps, use_graph=True, split=None):
+    prev = ocean.set_split_bf16(split) if split else None
+    try:
+        r = _train_cfg(name, N, S, deg, B, T, steps, use_graph)
+    finally:
+        if split:
+            ocean.set_split_bf16(prev)
+    if split:
+        r["arithmetic"] = f"SECONDARY: large convolution products split into bf16 halves ({split})"
+    return r
+
+
+def _train_cfg(name, N, S, deg, B, T, steps, use_graph=True):
     cfg, m, graph = make(N, S, deg)
     m.contrastive_negatives = "in_batch"
     learner = OnlineLearner(m, cfg)
@@ -150,3 +164,11 @@ for w in which:
         else:
             r = c5(use_graph)
         print(json.dumps(r), flush=True)
+    # the two training configurations once more, replayed, with only the backward products split (every parity test
+    # passes unchanged under that setting)
+    if w == "C2":
+        print(json.dumps(train_cfg("C2 online step (64 services, batch 256, seq_len 64, in-batch InfoNCE)", 64, 64, 4.0, 256, 64, 20, True,
+                                   split="backward")), flush=True)
+    elif w == "C4":
+        print(json.dumps(train_cfg("C4 one GPU's share (4096 services, in-degree 8, batch 64 of 512, seq_len 128, in-batch InfoNCE)", 4096,
+                                   4096, 8.0, 64, 128, 10, True, split="backward")), flush=True)
