@@ -397,10 +397,16 @@ int ocean_infonce_rows_bwd(const ocean_infonce_shape* s, const float* anchor, co
  *    1.32 M floats and fits); larger problems are refused with status 5 (use ocean_infonce_fwd);
  *  - each GPU holds one copy of the array (6 MB) from the library's load to the end of the process, shared by every call
  *    on that GPU: calls that overlap on one GPU (two streams, two threads) race on it - serialise them;
- *  - the backward pass needs the state the forward leaves in its workspace, so this variant is forward-only. */
+ *  - the backward pass needs the state the forward leaves in its workspace, so this variant is forward-only;
+ *  - `stream` must belong to the CURRENT device (the array's copy on the current device is the one used);
+ *  - the first call on a device looks the array's address up (hipGetSymbolAddress), which a stream capture in progress
+ *    may refuse: before recording this call into a HIP graph, call ocean_static_scratch_warmup() (or this entry point)
+ *    once on that device outside the capture. */
 #define OCEAN_STATIC_SCRATCH_FLOATS (1536 * 1024)
 int ocean_infonce_fwd_static(const ocean_infonce_shape* s, const float* anchor, const float* positive, const float* negatives,
                              float* loss /* ACCUMULATED, as in ocean_infonce_fwd */, void* stream);
+/* Resolves the built-in array's address for the current device; launches nothing.  No counterpart in the reference. */
+int ocean_static_scratch_warmup(void);
 
 /* The three in-batch pairs of ContrastiveLearningModule.forward in one call (graph_fusion.py:231-249 builds the pairs
  * (temporal, spatial), (temporal, log), (spatial, log) and calls InfoNCELoss.forward, :112-162, on each).

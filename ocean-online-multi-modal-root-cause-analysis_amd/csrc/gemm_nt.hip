@@ -457,6 +457,7 @@ bool ocean_gemm_nt_applies(const GemmBatch& b) {
   if (off || b.n != 1) return false;
   const GemmP& p = b.g[0];
   if (p.a_kmajor || p.b_kn || (p.taps != 1 && p.taps != 3)) return false;
+  if (p.taps == 1 && p.T > 0 && p.shift0 != 0) return false;              // the one-tap body reads its rows unshifted
   if (p.M % 128 != 0 || p.N % 64 != 0 || p.K % 16 != 0 || p.K < 32) return false;
   static const long min_tiles = [] { const char* e = getenv("OCEAN_GEMM_NT_MIN_TILES"); return e ? atol(e) : 256L; }();   // tuning knob
   if ((long)(p.M / 128) * (p.N % 128 == 0 ? p.N / 128 : p.N / 64) < min_tiles) return false;

@@ -375,6 +375,14 @@ static int static_scratch(float** out) {
   return OCEAN_OK;
 }
 
+// Looks the array's address up for the current device.  The lookup may load the code object, which a stream capture in
+// progress can refuse: a caller that records ocean_infonce_fwd_static into a HIP graph calls this (or the entry point
+// itself) once per device beforehand, outside the capture.
+int ocean_static_scratch_warmup(void) {
+  float* ws = nullptr;
+  return static_scratch(&ws);
+}
+
 int ocean_infonce_fwd_static(const ocean_infonce_shape* s, const float* anchor, const float* positive, const float* negatives,
                              float* loss, void* stream) {
   NcePlan pl;
@@ -523,15 +531,13 @@ __global__ __launch_bounds__(256) void mi_rows_kernel(const float* __restrict__ 
     atomicAdd(acc + 2 * (idx / B), joint);
     atomicAdd(acc + 2 * (idx / B) + 1, marg);
   }
+  __threadfence();      // every wave that added (a straddling block adds from all four) has its adds in L2 before the sign-off
   // The block that finishes last turns the sums into the estimates:
   // mi[m] = mean(joint scores) - log(mean(exp(shuffled scores)) + 1e-8)      (graph_fusion.py:497-499)
   // (acc[6] counts finished blocks; the sums are read with atomics, i.e. from L2, where every block's adds have landed)
   __shared__ int last;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    last = atomicAdd(reinterpret_cast<unsigned*>(acc + 6), 1u) == gridDim.x - 1;
-  }
+  if (threadIdx.x == 0) last = atomicAdd(reinterpret_cast<unsigned*>(acc + 6), 1u) == gridDim.x - 1;
   __syncthreads();
   if (last && threadIdx.x < 3) {
     const int m = threadIdx.x;

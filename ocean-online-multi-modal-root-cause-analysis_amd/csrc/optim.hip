@@ -51,21 +51,23 @@ __device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v
   p = p - step * m / (sqrtf(v) * rs2 + eps);
 }
 
-__global__ __launch_bounds__(256) void clip_adam_kernel(const ocean_adam_chunk* __restrict__ tab, int n_chunks, const double* __restrict__ sqnorm,
+// sqnorm and step_dev may point into / be written through `tail` by the block that finishes last, so neither they nor
+// `tail` are declared restrict or const-restrict, and both are read once, explicitly, before any chunk is touched.
+__global__ __launch_bounds__(256) void clip_adam_kernel(const ocean_adam_chunk* __restrict__ tab, int n_chunks, const double* sqnorm,
                                                         float max_norm, float lr, float b1, float b2, float eps, float wd,
                                                         float bc1, float bc2, int write_clipped,
-                                                        const float* __restrict__ lr_dev, const int* __restrict__ step_dev,
-                                                        ocean_adam_tail* __restrict__ tail) {
+                                                        const float* __restrict__ lr_dev, int* step_dev,
+                                                        ocean_adam_tail* tail) {
   int t_now = 0;
   if (lr_dev != nullptr) {     // learning rate and step count live on the device (HIP-graph replays)
     lr = lr_dev[0];
-    t_now = step_dev[0] + (tail != nullptr ? 1 : 0);      // with a tail the count is advanced here, not by the caller
+    t_now = __hip_atomic_load(step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (tail != nullptr ? 1 : 0);      // with a tail the count is advanced here, not by the caller
     const float t = (float)t_now;
     bc1 = 1.0f - powf(b1, t);
     bc2 = 1.0f - powf(b2, t);
   }
   float coef = 1.f;
-  const double sq_now = sqnorm ? sqnorm[0] : 0.0;
+  const double sq_now = sqnorm ? __hip_atomic_load(sqnorm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
   if (max_norm > 0.f && sqnorm) coef = fminf(1.f, max_norm / ((float)sqrt(sq_now) + 1e-6f));
   const float step = lr / bc1, rs2 = 1.0f / sqrtf(bc2);
   for (int q = blockIdx.x; q < n_chunks; q += gridDim.x) {
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(const ocean_adam_chunk* 
       tail->done = 0u;
       tail->sq_last = sq_now;
       tail->sq_acc = 0.0;
-      const_cast<int*>(step_dev)[0] = t_now;
+      step_dev[0] = t_now;
     }
   }
 }
@@ -130,7 +132,7 @@ int ocean_clip_adam_step(const ocean_adam_chunk* table, int n_chunks, const doub
   if (n_chunks <= 0 || step < 1) return OCEAN_ERR_BAD_SHAPE;
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(n_chunks < kAdamBlocks ? n_chunks : kAdamBlocks), dim3(256), 0, (hipStream_t)stream, table, n_chunks, sqnorm, max_norm, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2, write_clipped, (const float*)nullptr, (const int*)nullptr, (ocean_adam_tail*)nullptr);
+                     weight_decay, bc1, bc2, write_clipped, (const float*)nullptr, (int*)nullptr, (ocean_adam_tail*)nullptr);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }
@@ -141,7 +143,7 @@ int ocean_clip_adam_step_dev(const ocean_adam_chunk* table, int n_chunks, const 
   if (!table || !lr_dev || !step_dev) return OCEAN_ERR_NULL;
   if (n_chunks <= 0) return OCEAN_ERR_BAD_SHAPE;
   hipLaunchKernelGGL(clip_adam_kernel, dim3(n_chunks < kAdamBlocks ? n_chunks : kAdamBlocks), dim3(256), 0, (hipStream_t)stream, table, n_chunks, sqnorm, max_norm, 0.f, beta1, beta2, eps,
-                     weight_decay, 1.f, 1.f, write_clipped, lr_dev, step_dev, (ocean_adam_tail*)nullptr);
+                     weight_decay, 1.f, 1.f, write_clipped, lr_dev, const_cast<int*>(step_dev), (ocean_adam_tail*)nullptr);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }
@@ -157,7 +159,7 @@ int ocean_clip_adam_step_auto(const ocean_adam_chunk* table, int n_chunks, ocean
     OCEAN_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(clip_adam_kernel, dim3(n_chunks < kAdamBlocks ? n_chunks : kAdamBlocks), dim3(256), 0, (hipStream_t)stream, table, n_chunks, (const double*)&state->sq_acc, max_norm, 0.f,
-                     beta1, beta2, eps, weight_decay, 1.f, 1.f, write_clipped, lr_dev, (const int*)step_dev, state);
+                     beta1, beta2, eps, weight_decay, 1.f, 1.f, write_clipped, lr_dev, step_dev, state);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }

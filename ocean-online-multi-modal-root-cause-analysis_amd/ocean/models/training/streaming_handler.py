@@ -42,6 +42,10 @@ from .online_learner import OnlineLearner
 logger = logging.getLogger(__name__)
 
 
+class ShardedStepError(RuntimeError):
+    """A data-parallel update step failed on this rank in the middle of a sharded cycle; the rank has left the group."""
+
+
 class DataStream:
     def __init__(self, stream_id: str, buffer_size: int = 1000):
         self.stream_id, self.buffer_size = stream_id, buffer_size
@@ -160,6 +164,7 @@ class StreamProcessor:
         self._created = 0
         self.owner: Dict[str, int] = {}
         self.standin_steps = 0
+        self.failed: Optional[BaseException] = None     # set when a collective update step failed on this rank
         self.processing_interval, self.batch_size = processing_interval, batch_size
         self.event_driven = bool(event_driven)
         self.wake_samples = max(1, int(wake_samples if wake_samples is not None else batch_size))
@@ -230,9 +235,17 @@ class StreamProcessor:
         """One polling cycle: drain every active stream and update the model.  Returns samples processed."""
         t0 = time.time()
         samples: List[DatasetSample] = []
+        # sharded: a cycle's agreement message has room for MAX_CHUNKS chunks per rank, so no more than that many
+        # samples leave the stream buffers (the rest stay where they are for the next cycle)
+        room = self.MAX_CHUNKS * self.batch_size if self.world > 1 else None
         for stream in list(self.streams.values()):
             if stream.is_active and self.owns(stream.stream_id):
-                samples.extend(stream.get_samples(self.batch_size))
+                take = self.batch_size if room is None else min(self.batch_size, room - len(samples))
+                if take <= 0:
+                    break
+                samples.extend(stream.get_samples(take))
+        if self.failed is not None:
+            raise ShardedStepError("this rank left the data-parallel group after a failed update step") from self.failed
         if self.world > 1:
             done = self._process_samples_sharded(samples)
             if done == 0 and not samples:
@@ -266,6 +279,10 @@ class StreamProcessor:
                 while self.is_processing and remaining > 0:
                     time.sleep(min(0.05, remaining))
                     remaining = self.processing_interval - (time.time() - t0)
+            except ShardedStepError as e:        # this rank is out of step with its peers for good
+                logger.error("Stream processing stopped: %s", e)
+                self.is_processing = False
+                return
             except Exception as e:
                 logger.error("Error in stream processing: %s", e)
                 time.sleep(1.0)
@@ -289,19 +306,34 @@ class StreamProcessor:
     def _process_samples_sharded(self, samples: List[DatasetSample]) -> int:
         """One cycle of a rank among `world`: agree on the number of update steps (the largest chunk count of any rank)
         and on every rank's chunk sizes, then run that many steps - real chunks while this rank has some, weightless
-        stand-in batches after that.  Every rank calls this once per cycle, with or without samples."""
+        stand-in batches after that.  Every rank calls this once per cycle, with or without samples.
+
+        What can fail on one rank alone - collating a chunk of samples (ragged shapes, a sample without a tensor) -
+        happens BEFORE the agreement: such a chunk is logged and dropped as the reference drops a failing batch
+        (streaming_handler.py:355-356) and never enters the step count.  An update step itself is collective (BatchNorm
+        statistics, gathered rows, the gradient all-reduce): a rank that fails inside one cannot be skipped over without
+        leaving its peers waiting in a collective it never issues, so that error is not swallowed - the rank aborts its
+        process group (the peers' pending collectives then raise instead of blocking), stops processing and raises
+        ShardedStepError here and on every later cycle."""
         import torch
         dp = self.data_parallel
-        batches = [samples[i:i + self.batch_size] for i in range(0, len(samples), self.batch_size)][:self.MAX_CHUNKS]
-        if samples:
-            self._seq_len = int(samples[0].metrics.shape[0])
+        chunks = [samples[i:i + self.batch_size] for i in range(0, len(samples), self.batch_size)]
+        batches = []
+        for chunk in chunks:
+            try:
+                batches.append((len(chunk), chunk[0].graph, torch.stack([s.metrics for s in chunk]),
+                                torch.stack([s.logs for s in chunk]), torch.stack([s.label for s in chunk])))
+            except Exception as e:
+                logger.error("Error processing batch: %s", e)
+        if batches:
+            self._seq_len = int(batches[0][2].shape[1])
             if self.service_graph is None:
-                self.service_graph = samples[0].graph
+                self.service_graph = batches[0][1]
         # message: [chunk count, sequence length, chunk sizes ...]; one all-gather over the ranks
         msg = torch.zeros(2 + self.MAX_CHUNKS, dtype=torch.int64)
         msg[0], msg[1] = len(batches), self._seq_len
         for k, b in enumerate(batches):
-            msg[2 + k] = len(b)
+            msg[2 + k] = b[0]
         dev = self.online_learner.model.device
         table = torch.empty(self.world, msg.numel(), dtype=torch.int64, device=dev)
         dp.transport.all_gather(table, msg.to(dev))
@@ -317,19 +349,34 @@ class StreamProcessor:
                 dp.set_step_rows(rows)
                 try:
                     if k < len(batches):
-                        self.online_learner.process_batch(batches[k])
-                        done += len(batches[k])
+                        n, graph, metrics, logs, labels = batches[k]
+                        self.online_learner.process_tensors(metrics, graph, logs, labels)
+                        done += n
                     else:
                         if self.service_graph is None:
                             raise RuntimeError("a rank without samples needs the service graph for its stand-in batch: "
                                                "pass service_graph= to StreamingHandler / StreamProcessor")
                         self.online_learner.process_standin(seq_len, self.service_graph)
                         self.standin_steps += 1
-                except Exception as e:      # logged and skipped like the reference does (streaming_handler.py:355-356);
-                    logger.error("Error processing batch: %s", e)     # the other ranks' collectives may now be unmatched
+                except Exception as e:
+                    self._leave_group(e)
+                    raise ShardedStepError(f"update step {k} of a sharded cycle failed on rank {self.rank}: {e}") from e
         finally:
             dp.set_step_rows(None)
         return done
+
+    def _leave_group(self, exc: BaseException) -> None:
+        """A collective update step failed on this rank: stop processing and abort the process group so that the other
+        ranks' collectives end with an error instead of waiting for messages this rank will never send."""
+        self.failed = exc
+        self.is_processing = False
+        logger.error("Rank %d: update step failed inside a sharded cycle (%s); aborting the process group", self.rank, exc)
+        abort = getattr(self.data_parallel.transport, "abort", None)
+        if abort is not None:
+            try:
+                abort()
+            except Exception as e:          # nothing more to do than say so: the peers then end on their own timeout
+                logger.error("Rank %d: aborting the process group failed: %s", self.rank, e)
 
     def get_processing_stats(self) -> Dict[str, Any]:
         stats: Dict[str, Any] = {"total_processed_samples": self.processed_samples,

@@ -76,6 +76,16 @@ class Transport:
     def barrier(self) -> None:
         dist.barrier(group=self.group)
 
+    def abort(self) -> None:
+        """End this rank's part in the group now: collectives its peers have pending fail instead of blocking.  For a rank
+        that cannot complete a collective step (an error between two of its collectives)."""
+        pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
+        aborter = getattr(dist.distributed_c10d, "_abort_process_group", None)
+        if self.backend == "nccl" and aborter is not None:
+            aborter(pg)
+        else:
+            pg.shutdown() if hasattr(pg, "shutdown") else dist.destroy_process_group(pg)
+
     def quiesce(self) -> None:
         """Before a step with collectives is recorded into a HIP graph: wait until the process group's watchdog thread has
         retired every collective issued so far.  The watchdog polls the events of pending collectives on its own

@@ -136,6 +136,30 @@ def test_dilated_conv_window(B, Cin, Cout, d, flip, T):
     _close(out, ref.view(M, Cout))
 
 
+@pytest.mark.parametrize("shift", [3, -5])
+def test_single_tap_row_shift_at_a_large_aligned_size(shift):
+    """One tap with a row shift (out[b, t] = x[b, t + shift] W^T, zero outside the sample) at a size whose tiles are all
+    full and fill the chip: the k-contiguous kernel's one-tap body reads rows unshifted, so this problem must be served
+    by a kernel that honours the shift."""
+    from ocean import _hip
+    B, T, Cin, Cout = 256, 128, 64, 128
+    M = B * T
+    x, w = _rand(M, Cin, seed=1), _rand(Cout, Cin, seed=2) * 0.1
+    xd, wd = x.cuda(), w.cuda()
+    out = torch.full((M, Cout), float("nan"), device="cuda")
+    rc = _hip.lib().ocean_conv_gemm_f32(xd.data_ptr(), Cin, wd.data_ptr(), Cin, out.data_ptr(), Cout, M, Cout, Cin, 0, 0, 1, T, shift, 0,
+                                        0, 0, 1, _hip.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    xs = x.double().view(B, T, Cin)
+    sh = torch.zeros_like(xs)
+    if shift >= 0:
+        sh[:, :T - shift] = xs[:, shift:]
+    else:
+        sh[:, -shift:] = xs[:, :T + shift]
+    _close(out, (sh @ w.double().t()).view(M, Cout))
+
+
 def test_window_kernel_random_shapes():
     """Seeded random shapes across the k-contiguous kernel's domain (tile widths 64 / 128, 1 / 2 / 4 samples per tile,
     odd and even numbers of 16-deep chunks, shifts up to the band width, both shift orders) against a float64 reference

@@ -127,8 +127,12 @@ class _ShardStubLearner:
     def __init__(self):
         self.model, self.calls = self._M(), []
 
-    def process_batch(self, batch, prefetch=None):
-        self.calls.append(("batch", len(batch)))
+    fail_on_rows = None                # a step with this many rows raises (a failure inside a collective step)
+
+    def process_tensors(self, metrics, graph, logs, labels):
+        if metrics.shape[0] == self.fail_on_rows:
+            raise RuntimeError("kernel fault stand-in")
+        self.calls.append(("batch", int(metrics.shape[0])))
         return {}
 
     def process_standin(self, seq_len, graph):
@@ -140,8 +144,13 @@ class _ShardStubDP:
     def __init__(self):
         from ocean.parallel import Transport
         self.transport = Transport()
+        self.aborted = 0
+        self.transport.abort = self._abort          # the test's process group must survive to be torn down in order
         self.rank, self.world = self.transport.rank, self.transport.world
         self.rows = []
+
+    def _abort(self):
+        self.aborted += 1
 
     def set_step_rows(self, rows):
         self.rows.append(rows)
@@ -159,7 +168,7 @@ def _shard_worker(rank, world, port, out):
             assert h.create_stream(f"s{s}", buffer_size=100)
         sp = h.stream_processor
         owned = [sid for sid in sp.streams if sp.owns(sid)]
-        sample = lambda: SimpleNamespace(metrics=torch.zeros(9, 3), graph="G")
+        sample = lambda: SimpleNamespace(metrics=torch.zeros(9, 3), logs=torch.zeros(5), label=torch.zeros(4), graph="G")
         # rank 0 receives 2 x 35 samples on its streams (s0, s2), rank 1 10 on one of its (s1); samples offered to a stream
         # another rank owns are turned away
         accepted = 0
@@ -191,3 +200,74 @@ def test_sharded_streams_agree_on_step_counts():
     # both ranks saw the same per-step row tables, and switched the weighting off again after each cycle
     assert r0["rows"] == r1["rows"] == [[32, 10], [32, 0], None, [6, 0], None]
     assert r0["standins"] == 0 and r1["standins"] == 2
+
+
+def _shard_failure_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from ocean.models.training import StreamingHandler
+        from ocean.models.training.streaming_handler import ShardedStepError, StreamProcessor
+        learner, dp = _ShardStubLearner(), _ShardStubDP()
+        h = StreamingHandler(learner, max_concurrent_streams=4, processing_interval=0.05, data_parallel=dp, service_graph="G")
+        for s in range(4):
+            assert h.create_stream(f"s{s}", buffer_size=5000)
+        sp = h.stream_processor
+        good = lambda T=9: SimpleNamespace(metrics=torch.zeros(T, 3), logs=torch.zeros(5), label=torch.zeros(4), graph="G")
+        # cycle 1: rank 0 holds one chunk whose samples do not stack (two sequence lengths) and one good chunk of 7;
+        # rank 1 holds one good chunk of 3.  The ragged chunk is dropped before the ranks agree: one step, rows [7, 3].
+        if rank == 0:
+            for i in range(32):
+                h.add_sample_to_stream("s0", good(9 if i else 8))
+            for _ in range(7):
+                h.add_sample_to_stream("s2", good())
+        else:
+            for _ in range(3):
+                h.add_sample_to_stream("s1", good())
+        done1 = sp.process_once()
+        rows1 = list(dp.rows)
+        # cycle 2: more samples wait on rank 0 than one cycle's message has room for; the surplus stays buffered
+        sp.MAX_CHUNKS, room = 2, 2 * sp.batch_size
+        if rank == 0:
+            for _ in range(40):
+                h.add_sample_to_stream("s0", good())
+                h.add_sample_to_stream("s2", good())
+        done2 = sp.process_once()
+        left = sum(len(s.buffer) for s in sp.streams.values())
+        done3 = sp.process_once()
+        sp.MAX_CHUNKS = StreamProcessor.MAX_CHUNKS
+        # cycle 4: rank 1's step fails inside the (collective) update: not swallowed
+        learner.fail_on_rows = 5 if rank == 1 else None
+        for _ in range(5):
+            h.add_sample_to_stream("s0" if rank == 0 else "s1", good())
+        err = again = None
+        try:
+            sp.process_once()
+        except ShardedStepError as e:
+            err = str(e)
+        if rank == 1:
+            try:
+                sp.process_once()
+            except ShardedStepError as e:
+                again = str(e)
+        out[rank] = {"done": (done1, done2, done3), "rows1": rows1, "left": left, "room": room, "err": err, "again": again,
+                     "aborted": dp.aborted, "failed": sp.failed is not None, "calls": learner.calls}
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_streams_failures_and_surplus():
+    """What one rank can get wrong alone (a chunk that does not collate) is dropped before the ranks agree on the cycle's
+    steps; samples beyond the agreement message's room stay in their buffers; an error inside a collective update step
+    is raised, marks the processor failed and aborts the group instead of leaving the peers in unmatched collectives."""
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_shard_failure_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["rows1"] == r1["rows1"] == [[7, 3], None]
+    assert r0["done"][0] == 7 and r1["done"][0] == 3
+    assert r0["done"][1] == r0["room"] and r0["left"] == 80 - r0["room"] and r0["done"][2] == 80 - r0["room"]
+    assert r0["err"] is None and not r0["failed"] and r0["aborted"] == 0
+    assert r1["err"] is not None and "rank 1" in r1["err"] and r1["failed"] and r1["aborted"] == 1
+    assert r1["again"] is not None

@@ -74,3 +74,31 @@ def test_sizes_beyond_the_array_are_refused_and_loss_accumulates():
     one = torch.zeros((), device="cuda")
     _hip.check(L.ocean_infonce_fwd_static(ctypes.byref(sh), _hip.dev_ptr(a), _hip.dev_ptr(p), None, _hip.dev_ptr(one), _hip.stream()), "static")
     assert abs(float(loss) - 2 * float(one)) <= 1e-6 * abs(float(loss))
+
+
+def test_recorded_into_a_hip_graph_after_a_warm_up():
+    """The use the entry point exists for: after ocean_static_scratch_warmup() outside the capture, the call is recorded
+    into a HIP graph (no allocation, no symbol lookup inside) and every replay adds the loss of the current inputs."""
+    from ocean import _hip
+    L = _hip.lib()
+    _hip.check(L.ocean_static_scratch_warmup(), "ocean_static_scratch_warmup")
+    B, P = 64, 32
+    sh = _shape(B, B, P, 0)
+    g = torch.Generator().manual_seed(11)
+    a, p = torch.randn(B, P, generator=g).cuda(), torch.randn(B, P, generator=g).cuda()
+    loss = torch.zeros((), device="cuda")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with _hip.capture(graph):
+        _hip.check(L.ocean_infonce_fwd_static(ctypes.byref(sh), _hip.dev_ptr(a), _hip.dev_ptr(p), None, _hip.dev_ptr(loss), _hip.stream()),
+                   "ocean_infonce_fwd_static under capture")
+    ws = torch.empty(L.ocean_infonce_workspace(ctypes.byref(sh)), device="cuda", dtype=torch.float32)
+    for step in range(2):
+        ref = torch.zeros((), device="cuda")
+        _hip.check(L.ocean_infonce_fwd(ctypes.byref(sh), _hip.dev_ptr(a), _hip.dev_ptr(p), None, _hip.dev_ptr(ws), ws.numel(),
+                                       _hip.dev_ptr(ref), _hip.stream()), "ocean_infonce_fwd")
+        loss.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        _check(float(ref), float(loss))
+        a.copy_(torch.randn(B, P, generator=g))          # the next replay reads the new anchors in place
