@@ -133,32 +133,62 @@ def cpu_baseline(model, nf, adj, T, S, budget_s=25.0):
 
 def launch_ranks(n, argv):
     """Start n rank processes of this script (this process has not touched a GPU and does not), wait for them and
-    return the worst exit code.  Rank 0's stdout (the JSON line) passes through."""
+    return the worst exit code.  Rank 0's stdout (the JSON line) passes through; every rank's stderr goes to its own
+    file (OCEAN_BENCH_LOG_DIR, default a fresh temporary directory), and the tail of a failing rank's file is repeated
+    on this process's stderr with the rank named.  A run that exceeds OCEAN_BENCH_TIMEOUT seconds (default 900) of wall
+    clock - a collective some rank never entered - is ended here with exit code 124 and the list of ranks that were
+    still running, instead of waiting for the collective's own timeout."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    log_dir = os.environ.get("OCEAN_BENCH_LOG_DIR") or tempfile.mkdtemp(prefix="ocean_bench_")
+    os.makedirs(log_dir, exist_ok=True)
+    limit = float(os.environ.get("OCEAN_BENCH_TIMEOUT", "900"))
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+        logs.append(os.path.join(log_dir, f"rank{r}.err"))
+        with open(logs[-1], "wb") as err:
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stderr=err))
+
+    def tail(r, lines=25):
+        try:
+            with open(logs[r], "rb") as f:
+                text = f.read().decode(errors="replace").splitlines()[-lines:]
+        except OSError:
+            text = []
+        print(f"[bench.py] rank {r} stderr ({logs[r]}), last lines:", file=sys.stderr)
+        for ln in text:
+            print(f"[rank {r}] {ln}", file=sys.stderr)
+
     # wait for all of them; when one fails, the others (stuck in a collective that will never complete) are stopped
     # instead of being waited for until the collective's own timeout
-    worst, live = 0, list(procs)
+    worst, live, t0 = 0, list(range(n)), time.time()
     while live:
         time.sleep(0.2)
-        for p in list(live):
-            rc = p.poll()
+        for r in list(live):
+            rc = procs[r].poll()
             if rc is None:
                 continue
-            live.remove(p)
+            live.remove(r)
             if rc != 0 and worst == 0:
                 worst = rc
+                print(f"[bench.py] rank {r} exited with code {rc}; stopping ranks {live}", file=sys.stderr)
+                tail(r)
                 for other in live:
-                    other.terminate()
+                    procs[other].terminate()
+        if live and worst == 0 and time.time() - t0 > limit:
+            worst = 124
+            print(f"[bench.py] no result after {limit:.0f} s; ranks still running: {live} (stopping them)", file=sys.stderr)
+            for r in live:
+                tail(r, 12)
+                procs[r].terminate()
+    sys.stderr.flush()
     return worst
 
 
@@ -199,8 +229,11 @@ def main():
     rehearse = os.environ.get("OCEAN_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
+    if world > 1 or rehearse:
+        # a rank stuck in a collective dumps every thread's stack into its stderr and exits non-zero, under whichever
+        # launcher it runs (this script's own or torch.distributed.run)
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ.get("OCEAN_BENCH_REHEARSE_TIMEOUT", "120")), exit=True)   # a stuck collective names itself
+        faulthandler.dump_traceback_later(int(os.environ.get("OCEAN_BENCH_RANK_TIMEOUT", os.environ.get("OCEAN_BENCH_REHEARSE_TIMEOUT", "600"))), exit=True)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # OCEAN_BENCH_DIST=1 takes the data-parallel code path (RCCL process group, collectives) with a single rank as

@@ -25,7 +25,6 @@ takes part with weight 0.
 from __future__ import annotations
 
 import os
-import time
 from typing import List, Optional
 
 import torch
@@ -87,14 +86,12 @@ class Transport:
             pg.shutdown() if hasattr(pg, "shutdown") else dist.destroy_process_group(pg)
 
     def quiesce(self) -> None:
-        """Before a step with collectives is recorded into a HIP graph: wait until the process group's watchdog thread has
-        retired every collective issued so far.  The watchdog polls the events of pending collectives on its own
-        schedule (it wakes at least every 100 ms); a poll that falls into a stream capture is refused by the HIP runtime,
-        the exception ends the watchdog thread and with it the process (seen about once in ten recordings).  There is no
-        call that waits for its list to empty, so: finish the device's work, then give it three of its periods."""
+        """Before a step with collectives is recorded into a HIP graph: finish the device's work, so that every
+        collective of the eager steps has completed before the recording starts.  (The process group's watchdog thread
+        goes on polling the events of collectives it still lists; ocean._hip.capture records in thread-local capture
+        mode, in which the runtime refuses unsafe calls of the recording thread only, so those polls are legal.)"""
         if self.backend == "nccl":
             torch.cuda.synchronize()
-            time.sleep(0.3)
 
 
 class _ThenScale:

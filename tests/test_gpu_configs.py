@@ -123,7 +123,8 @@ def test_large_graph_update_step_matches_oracle(B, all_replicas):
     rl["total_loss"].backward()
     if B > 8:
         import torch.nn.functional as F
-        rsd64 = R.require_grad({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+        from parity_rules import gradient_gate, to_double
+        rsd64 = R.require_grad(to_double(sd))
         ro64 = R.model_forward(rsd64, metrics.double(), None, nf.double(), logs.double(), training=True, negatives="in_batch", edge_index=ei)
         (F.binary_cross_entropy(ro64["root_cause_probs"], labels.double()) + 0.1 * sum(ro64["contrastive_losses"].values())).backward()
     # HIP path
@@ -142,14 +143,10 @@ def test_large_graph_update_step_matches_oracle(B, all_replicas):
             # get exact zeros (the reference's autograd does the same; the oracle leaves them out of its graph)
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
-        if B > 8 and k.startswith("temporal_encoder."):
-            # 8192 rows through seven ReLUs: a pre-activation within rounding of zero takes either sign depending on the
-            # summation order, and one such element moves a column sum of the BatchNorm backward by its full size.  Against
-            # the same oracle run in fp64 the fp32 CPU oracle itself is 6e-4 off (2-norm) on every tensor of this encoder
-            # and this path 2e-4 .. 2.7e-3 (tools/diag_c4_grad.py), so 1e-3 against the fp32 oracle is not a bound either
-            # side can keep here; the fp64 oracle is the yardstick, at 5e-3.
-            g, r = p.grad.detach().double().cpu(), rsd64[k].grad
-            assert (g - r).norm().item() <= 5e-3 * max(r.norm().item(), 1e-12), k
+        if B > 8:
+            # 8192 and more rows through seven ReLUs: the large-row rule (tests/parity_rules.py) - the plain 1e-3 gate
+            # wherever the fp32 CPU oracle itself is within 5e-4 of its fp64 run, else at most 1.5 x the CPU's own distance
+            gradient_gate(k, p.grad, rsd[k].grad, rsd64[k].grad)
             continue
         close(p.grad, rsd[k].grad, 1e-3, k)
     # the update itself: clip + Adam against the oracle's
@@ -266,6 +263,72 @@ def test_sixty_four_streams_threaded_event_driven():
     assert all(torch.isfinite(p).all() for p in m.parameters())
 
 
+# ---------------------------------------------------------------- whole update steps at full size
+def _oracle_step_fp32_and_fp64(sd, metrics, adj, nf, logs, labels):
+    """The oracle's in-batch training forward + compute_loss + backward in fp32 and again in fp64 (the yardstick of the
+    large-row rule).  Returns (fp32 probabilities, fp32 loss dict, fp32 tensors with .grad, fp64 tensors with .grad)."""
+    import torch.nn.functional as F
+    from parity_rules import to_double
+    rsd = R.require_grad(sd)
+    ro = R.model_forward(rsd, metrics, adj, nf, logs, training=True, negatives="in_batch")
+    rl = R.compute_loss(ro, labels)
+    rl["total_loss"].backward()
+    rprobs = ro["root_cause_probs"].detach()
+    rl = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in rl.items()}
+    del ro
+    rsd64 = R.require_grad(to_double(sd))
+    ro64 = R.model_forward(rsd64, metrics.double(), adj.double(), nf.double(), logs.double(), training=True, negatives="in_batch")
+    (F.binary_cross_entropy(ro64["root_cause_probs"], labels.double()) + 0.1 * sum(ro64["contrastive_losses"].values())).backward()
+    del ro64
+    return rprobs, rl, rsd, rsd64
+
+
+def test_c2_full_size_matches_oracle():
+    """The single-GPU online-training configuration at its stated size: 64 services, batch 256, 64 timesteps, in-batch
+    InfoNCE, dropout 0.  Probabilities 1e-4 relative, identical top-k, the three losses and the gradient norm 1e-3, every
+    gradient tensor by the large-row rule (16 384 rows), the dead query / key projections exact zeros."""
+    import ocean
+    from ocean.data import ServiceGraph
+    from ocean.optim import FusedAdam
+    from parity_rules import gradient_gate
+    N, B, T = 64, 256, 64
+    cfg = ocean.default_config()
+    cfg.model.num_services = N
+    m = ocean.OCEANModel(cfg)
+    zero_dropout(m)
+    sd = synth.fill_state_dict(m.state_dict(), 47)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    m.contrastive_negatives = "in_batch"
+    gen = torch.Generator().manual_seed(12)
+    adj, nf = synth.random_digraph(N, 4.0, 11), torch.randn(N, 12, generator=gen)
+    metrics, logs = torch.randn(B, T, 12, generator=gen), torch.randn(B, 768, generator=gen)
+    labels = torch.zeros(B, N)
+    labels[torch.arange(B), torch.randint(0, N, (B,), generator=gen)] = 1.0
+    out = m(metrics, ServiceGraph(adj, nf), logs)
+    losses = m.compute_loss(out, labels.cuda())
+    losses["total_loss"].backward()
+    opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    opt.step(max_norm=1.0, write_clipped=False)
+    gnorm = float(opt.grad_norm())
+    got = {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    probs = out["root_cause_probs"].detach().cpu()
+    rprobs, rl, rsd, rsd64 = _oracle_step_fp32_and_fp64(sd, metrics, adj, nf, logs, labels)
+    assert ((probs - rprobs).abs() / rprobs).max().item() < 1e-4
+    for k in (1, 3, 5, 10):
+        assert torch.equal(torch.topk(probs, k, dim=-1).indices, torch.topk(rprobs, k, dim=-1).indices), k
+    for k in ("total_loss", "prediction_loss", "contrastive_loss"):
+        close(losses[k], rl[k], 1e-3, k)
+    tk = [k for k in R.trainable_keys(rsd) if rsd[k].grad is not None]
+    rnorm = torch.sqrt(sum((rsd[k].grad.double() ** 2).sum() for k in tk)).item()
+    assert abs(gnorm - rnorm) <= 1e-3 * rnorm, (gnorm, rnorm)
+    for k in set(got) - set(tk):
+        assert float(got[k].abs().max()) == 0.0, k
+    assert set(tk) <= set(got)
+    for k in tk:
+        gradient_gate(k, got[k], rsd[k].grad, rsd64[k].grad)
+
+
 # ---------------------------------------------------------------- the headline shape, once, at full size
 def test_headline_shape_full_size_matches_oracle():
     """Batch 1024 x 128 timesteps x 256 services: 131 072-row BatchNorm statistics and split weight-gradient reductions,
@@ -274,6 +337,7 @@ def test_headline_shape_full_size_matches_oracle():
     import ocean
     from ocean.data import ServiceGraph
     from ocean.optim import FusedAdam
+    from parity_rules import gradient_gate
     N, B, T = 256, 1024, 128
     cfg = ocean.default_config()
     cfg.model.num_services = N
@@ -299,11 +363,7 @@ def test_headline_shape_full_size_matches_oracle():
     host_losses = {k: float(losses[k].detach()) for k in ("total_loss", "prediction_loss", "contrastive_loss")}
     del out, losses
     torch.cuda.empty_cache()
-    rsd = R.require_grad(sd)
-    ro = R.model_forward(rsd, metrics, adj, nf, logs, training=True, negatives="in_batch")
-    rl = R.compute_loss(ro, labels)
-    rl["total_loss"].backward()
-    rprobs = ro["root_cause_probs"].detach()
+    rprobs, rl, rsd, rsd64 = _oracle_step_fp32_and_fp64(sd, metrics, adj, nf, logs, labels)
     assert ((probs - rprobs).abs() / rprobs).max().item() < 1e-4
     for k in (1, 3, 5, 10):
         assert torch.equal(torch.topk(probs, k, dim=-1).indices, torch.topk(rprobs, k, dim=-1).indices), k
@@ -315,8 +375,12 @@ def test_headline_shape_full_size_matches_oracle():
     for k in set(got) - set(tk):                # the dead query / key projections: exact zeros, as in the reference
         assert float(got[k].abs().max()) == 0.0, k
     assert set(tk) <= set(got)
+    report = []
     for k in tk:
-        close(got[k], rsd[k].grad, 1e-3, k)
+        gradient_gate(k, got[k], rsd[k].grad, rsd64[k].grad, report)
+    loose = [r for r in report if not r[3].startswith("max-norm")]
+    print(f"{len(report) - len(loose)} of {len(report)} gradient tensors held to max-norm 1e-3 against the fp32 oracle; "
+          + "; ".join(f"{n}: gpu {a:.1e} cpu32 {b:.1e} ({w})" for n, a, b, w in loose))
 
 
 def test_eval_outputs_do_not_depend_on_batch_composition_or_order():
