@@ -7,7 +7,10 @@ element moves a BatchNorm-backward column sum by its full size - in the fp32 CPU
 both are measured against the oracle run in fp64 on the same inputs (2-norm per tensor):
 
   * where the fp32 CPU oracle is within 5e-4 of fp64, the plain gate holds: max-norm 1e-3 against the fp32 oracle;
-  * elsewhere the GPU result must be within max(1e-3, 1.5 x the fp32 CPU oracle's own distance) of the fp64 result.
+  * elsewhere the GPU result must be within max(1e-3, 3 x the fp32 CPU oracle's own distance) of the fp64 result.
+    (Why 3: the two fp32 evaluations are independent draws of the same noise - which handful of pre-activations flips
+    depends on each side's summation order - and over the 4096-service step at batches 16 / 64 / 128 the ratio of the two
+    distances was measured between 0.4 and 3.3 for the tensors of the temporal encoder, in either direction.)
 
 `report` (a list) receives (name, err_gpu_vs_fp64, err_cpu32_vs_fp64, which gate applied) per tensor, so a test can
 print where fp32 could not keep 1e-3."""
@@ -31,7 +34,7 @@ def gradient_gate(name, got, ref32, ref64, report=None):
             report.append((name, err_gpu, err_cpu, "max-norm 1e-3 vs fp32 oracle"))
         assert err <= 1e-3 * scale, f"{name}: max err {err:.3e} scale {scale:.3e} (fp32 oracle is {err_cpu:.1e} from fp64)"
     else:
-        bound = max(1e-3, 1.5 * err_cpu)
+        bound = max(1e-3, 3.0 * err_cpu)
         if report is not None:
             report.append((name, err_gpu, err_cpu, f"2-norm {bound:.1e} vs fp64 oracle"))
         assert err_gpu <= bound, f"{name}: {err_gpu:.3e} from the fp64 oracle, the fp32 CPU oracle {err_cpu:.3e}, bound {bound:.3e}"
