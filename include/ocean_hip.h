@@ -408,6 +408,12 @@ int ocean_infonce_fwd_static(const ocean_infonce_shape* s, const float* anchor, 
 /* Resolves the built-in array's address for the current device; launches nothing.  No counterpart in the reference. */
 int ocean_static_scratch_warmup(void);
 
+/* Diagnostics of the stage kernels (the attention / fusion / head chains that small batches run as one launch each; no
+ * counterpart in the reference): while `buffer` - device memory of at least 60 64-bit words, or NULL to stop - is set,
+ * block 0 of every such kernel writes (operation kind * 1000 + width, 100 MHz clock stamp) per operation, then
+ * (-1, stamp at the end).  Not thread-safe; for measurement scripts. */
+void ocean_rc_debug_trace(void* buffer);
+
 /* The three in-batch pairs of ContrastiveLearningModule.forward in one call (graph_fusion.py:231-249 builds the pairs
  * (temporal, spatial), (temporal, log), (spatial, log) and calls InfoNCELoss.forward, :112-162, on each).
  * Z [3, B, P] holds the three projections; losses[q] is ACCUMULATED (+= mean over B rows) for pair q in that order.

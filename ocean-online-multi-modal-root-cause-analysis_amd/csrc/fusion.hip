@@ -9,6 +9,8 @@
 // (mean_l(W o_l + b) = W mean_l(o_l) + b), so out_proj runs on [B,E] rows.
 #include "../../include/ocean_hip.h"
 #include "ops.h"
+#include "rowbodies.h"
+#include "rowchain.h"
 
 namespace {
 
@@ -110,66 +112,17 @@ __global__ void mha3_bwd_kernel(const float* __restrict__ dOm, const float* __re
   }
 }
 
-// One wave per sample for the usual shapes (E = 64 * VEC columns, a power-of-two head count): lane l owns columns
-// l*VEC .. l*VEC+VEC-1 of every row, the 64/H lanes of a head reduce their partial dot products with xor shuffles, and
-// every load and store of a wave is one contiguous row.  (One thread per (sample, head) leaves 8192 threads on the
-// whole chip walking 128-byte strides: 33 + 53 us for a few MB.)
-template <int VEC>
-__device__ __forceinline__ void ldv(const float* p, float (&v)[VEC]) {
-  if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-  else if constexpr (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
-  else { v[0] = p[0]; }
-}
-template <int VEC>
-__device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
-  if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-  else if constexpr (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
-  else p[0] = v[0];
-}
-
+// One wave per sample for the usual shapes (E = 64 * VEC columns, a power-of-two head count): rowbody::mha3_*_sample.
+// (One thread per (sample, head) leaves 8192 threads on the whole chip walking 128-byte strides: 33 + 53 us for a few MB.)
+using rowbody::mha3_hlog;
+using rowbody::mha3_vec;
 template <int VEC>
 __global__ __launch_bounds__(256) void mha3_fwd_wave_kernel(const float* __restrict__ qkv, float* __restrict__ probs, float* __restrict__ o,
                                                             int B, int H, int hlog, DropoutP dp) {
   dp = dropout_resolve(dp);
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;                                   // wave-uniform
-  const int E = 64 * VEC, lph = 64 >> hlog, h = lane >> (6 - hlog), c = lane * VEC;
-  const float sc = 1.0f / sqrtf((float)(lph * VEC));
-  const float* base = qkv + (long)b * kTok * 3 * E + c;
-  float q[kTok][VEC], k[kTok][VEC], v[kTok][VEC];
-#pragma unroll
-  for (int i = 0; i < kTok; ++i) { ldv<VEC>(base + (long)i * 3 * E, q[i]); ldv<VEC>(base + (long)i * 3 * E + E, k[i]); ldv<VEC>(base + (long)i * 3 * E + 2 * E, v[i]); }
-  float S[kTok][kTok];
-#pragma unroll
-  for (int i = 0; i < kTok; ++i)
-#pragma unroll
-    for (int j = 0; j < kTok; ++j) {
-      float t = 0.f;
-#pragma unroll
-      for (int u = 0; u < VEC; ++u) t = fmaf(q[i][u] * sc, k[j][u], t);
-      for (int sh = 1; sh < lph; sh <<= 1) t += __shfl_xor(t, sh);
-      S[i][j] = t;
-    }
-  const int idx = b * H + h;
-  float A[kTok][kTok];
-#pragma unroll
-  for (int i = 0; i < kTok; ++i) {
-    const float m = fmaxf(S[i][0], fmaxf(S[i][1], S[i][2]));
-    const float e0 = __expf(S[i][0] - m), e1 = __expf(S[i][1] - m), e2 = __expf(S[i][2] - m), es = e0 + e1 + e2;
-    A[i][0] = e0 / es; A[i][1] = e1 / es; A[i][2] = e2 / es;
-#pragma unroll
-    for (int j = 0; j < kTok; ++j) {
-      if ((lane & (lph - 1)) == 0) probs[((long)idx * kTok + i) * kTok + j] = A[i][j];
-      if (dp.p > 0.f) A[i][j] *= dropout_keep(dp, ((uint64_t)idx * kTok + i) * kTok + j);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < kTok; ++i) {
-    float r[VEC];
-#pragma unroll
-    for (int u = 0; u < VEC; ++u) r[u] = A[i][0] * v[0][u] + A[i][1] * v[1][u] + A[i][2] * v[2][u];
-    stv<VEC>(o + ((long)b * kTok + i) * E + c, r);
-  }
+  rowbody::mha3_fwd_sample<VEC>(qkv, probs, o, H, hlog, dp, b, lane);
 }
 
 template <int VEC>
@@ -179,64 +132,8 @@ __global__ __launch_bounds__(256) void mha3_bwd_wave_kernel(const float* __restr
   dp = dropout_resolve(dp);
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;                                   // wave-uniform
-  const int E = 64 * VEC, lph = 64 >> hlog, h = lane >> (6 - hlog), c = lane * VEC;
-  const float sc = 1.0f / sqrtf((float)(lph * VEC));
-  const float* base = qkv + (long)b * kTok * 3 * E + c;
-  float* dbase = dqkv + (long)b * kTok * 3 * E + c;
-  const int idx = b * H + h;
-  float q[kTok][VEC], k[kTok][VEC], v[kTok][VEC], g[VEC];
-#pragma unroll
-  for (int i = 0; i < kTok; ++i) { ldv<VEC>(base + (long)i * 3 * E, q[i]); ldv<VEC>(base + (long)i * 3 * E + E, k[i]); ldv<VEC>(base + (long)i * 3 * E + 2 * E, v[i]); }
-  ldv<VEC>(dOm + (long)b * E + c, g);
-#pragma unroll
-  for (int u = 0; u < VEC; ++u) g[u] *= (1.0f / kTok);
-  float A[kTok][kTok], Ad[kTok][kTok], keep[kTok][kTok];
-#pragma unroll
-  for (int i = 0; i < kTok; ++i)
-#pragma unroll
-    for (int j = 0; j < kTok; ++j) {
-      A[i][j] = probs[((long)idx * kTok + i) * kTok + j];
-      keep[i][j] = dp.p > 0.f ? dropout_keep(dp, ((uint64_t)idx * kTok + i) * kTok + j) : 1.f;
-      Ad[i][j] = A[i][j] * keep[i][j];
-    }
-  float dv_dot[kTok];
-#pragma unroll
-  for (int j = 0; j < kTok; ++j) {
-    float t = 0.f, dv[VEC];
-#pragma unroll
-    for (int u = 0; u < VEC; ++u) { t = fmaf(g[u], v[j][u], t); dv[u] = g[u] * (Ad[0][j] + Ad[1][j] + Ad[2][j]); }
-    for (int sh = 1; sh < lph; sh <<= 1) t += __shfl_xor(t, sh);
-    dv_dot[j] = t;
-    stv<VEC>(dbase + (long)j * 3 * E + 2 * E, dv);
-  }
-  float dS[kTok][kTok];
-#pragma unroll
-  for (int i = 0; i < kTok; ++i) {
-    float dA[kTok], dot = 0.f;
-#pragma unroll
-    for (int j = 0; j < kTok; ++j) { dA[j] = dv_dot[j] * keep[i][j]; dot += A[i][j] * dA[j]; }
-#pragma unroll
-    for (int j = 0; j < kTok; ++j) dS[i][j] = A[i][j] * (dA[j] - dot);
-  }
-#pragma unroll
-  for (int i = 0; i < kTok; ++i) {
-    float dq[VEC], dk[VEC];
-#pragma unroll
-    for (int u = 0; u < VEC; ++u) {
-      dq[u] = sc * (dS[i][0] * k[0][u] + dS[i][1] * k[1][u] + dS[i][2] * k[2][u]);
-      dk[u] = sc * (dS[0][i] * q[0][u] + dS[1][i] * q[1][u] + dS[2][i] * q[2][u]);
-    }
-    stv<VEC>(dbase + (long)i * 3 * E, dq);
-    stv<VEC>(dbase + (long)i * 3 * E + E, dk);
-  }
+  rowbody::mha3_bwd_sample<VEC>(dOm, qkv, probs, dqkv, H, hlog, dp, b, lane);
 }
-
-// wave-per-sample variants apply: E = 64, 128 or 256 columns and a power-of-two head count of at most 64
-inline int mha3_vec(int E, int H) {
-  if (H <= 0 || H > 64 || (H & (H - 1)) != 0) return 0;
-  return E == 256 ? 4 : E == 128 ? 2 : E == 64 ? 1 : 0;
-}
-inline int mha3_hlog(int H) { int l = 0; while ((1 << l) < H) ++l; return l; }
 
 struct FusPlan {
   int B, E, Pd;
@@ -302,6 +199,7 @@ int ocean_fusion_fwd(const ocean_fusion_shape* s, const float* t, const float* s
   const float* xin[3] = {t, sp, lg};
   const int xd[3] = {s->td, s->sd, s->ld};
   const DropoutP none = {0.f, 0, nullptr};
+  RcScope rc(B, st);       // small batches: the whole chain below becomes one launch (rowchain.h)
   // the three modality branches run as one launch per layer
   LinFwd l[3];
   for (int m = 0; m < 3; ++m) l[m] = LinFwd{xin[m], xd[m], P_[4 * m], P_[4 * m + 1], ws + pl.R + m * BE, E, B, E, xd[m]};
@@ -317,10 +215,19 @@ int ocean_fusion_fwd(const ocean_fusion_shape* s, const float* t, const float* s
     for (int m = 0; m < 3; ++m)
       l[m] = LinFwd{ws + pl.Y1 + m * BE, E, P_[24 + 4 * m], P_[25 + 4 * m], ws + pl.Y2 + (size_t)m * B * Pd, Pd, B, Pd, E};
     OCEAN_TRY(linear_fwd_batch(l, 3, 0, st));
-    OCEAN_TRY(l2norm_fwd(ws + pl.Y2, Pd, Zp, Pd, ws + pl.nrm, 3 * B, Pd, 1e-12f, st));
+    if (rc_active()) {      // the stage kernel walks samples: the [3][B][.] stack is three matrices of one row per sample
+      for (int m = 0; m < 3; ++m)
+        OCEAN_TRY(l2norm_fwd(ws + pl.Y2 + (size_t)m * B * Pd, Pd, Zp + (size_t)m * B * Pd, Pd, ws + pl.nrm + (size_t)m * B, B, Pd, 1e-12f, st));
+    } else {
+      OCEAN_TRY(l2norm_fwd(ws + pl.Y2, Pd, Zp, Pd, ws + pl.nrm, 3 * B, Pd, 1e-12f, st));
+    }
   }
-  OCEAN_TRY(linear_fwd(X, E, P_[12], P_[13], ws + pl.QKV, 3 * E, 3 * B, 3 * E, E, 0, st));
-  switch (mha3_vec(E, s->heads)) {
+  {
+    const RcTokenMajor tokens;      // X is [B, 3, E]: three consecutive rows per sample
+    OCEAN_TRY(linear_fwd(X, E, P_[12], P_[13], ws + pl.QKV, 3 * E, 3 * B, 3 * E, E, 0, st));
+  }
+  if (rc_mha3_fwd(ws + pl.QKV, ws + pl.probs, ws + pl.O, B, E, s->heads, site(s, 3))) {}
+  else switch (mha3_vec(E, s->heads)) {
     case 4: hipLaunchKernelGGL(mha3_fwd_wave_kernel<4>, dim3(ceil_div(B, 4)), dim3(256), 0, st, ws + pl.QKV, ws + pl.probs, ws + pl.O, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
     case 2: hipLaunchKernelGGL(mha3_fwd_wave_kernel<2>, dim3(ceil_div(B, 4)), dim3(256), 0, st, ws + pl.QKV, ws + pl.probs, ws + pl.O, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
     case 1: hipLaunchKernelGGL(mha3_fwd_wave_kernel<1>, dim3(ceil_div(B, 4)), dim3(256), 0, st, ws + pl.QKV, ws + pl.probs, ws + pl.O, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
@@ -336,7 +243,7 @@ int ocean_fusion_fwd(const ocean_fusion_shape* s, const float* t, const float* s
   Epi e4; e4.drop = &d4;
   OCEAN_TRY(linear_fwd(ws + pl.Fn, E, P_[18], P_[19], ws + pl.H1, E, B, E, E, 1, st, &e4));
   OCEAN_TRY(linear_fwd(ws + pl.H1, E, P_[20], P_[21], fused, E, B, E, E, 0, st));
-  return OCEAN_OK;
+  return rc.finish();
 }
 
 int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* sp, const float* lg, float* const* P_, float* wf,
@@ -351,6 +258,7 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* s
   const size_t BE = (size_t)B * E;
   const DropoutP none = {0.f, 0, nullptr};
   float* e1 = wb + pl.e1; float* e2 = wb + pl.e2; float* dX = wb + pl.dX;
+  RcScope rc(B, st);       // small batches: the data-gradient chain is one launch, the weight gradients another (rowchain.h)
   if (dfused) {
     const DropoutP d4 = site(s, 4);
     Epi e4; e4.drop = &d4; e4.relu_mask = wf + pl.H1; e4.ld_mask = E;   // dropout and ReLU backward on the way out of the dgrad GEMM
@@ -358,7 +266,8 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* s
     OCEAN_TRY(lin_bwd(wf + pl.Fn, E, e2, E, B, E, E, P_[18], G_[18], G_[19], e1, E, 0, st));
     OCEAN_TRY(layernorm_bwd(e1, E, wf + pl.Ao, E, wf + pl.lnsa, P_[16], e1, E, G_[16], G_[17], B, E, none, st));
     OCEAN_TRY(lin_bwd(wf + pl.Om, E, e1, E, B, E, E, P_[14], G_[14], G_[15], wb + pl.dOm, E, 0, st));
-    switch (mha3_vec(E, s->heads)) {
+    if (rc_mha3_bwd(wb + pl.dOm, wf + pl.QKV, wf + pl.probs, wb + pl.dQKV, B, E, s->heads, site(s, 3))) {}
+    else switch (mha3_vec(E, s->heads)) {
       case 4: hipLaunchKernelGGL(mha3_bwd_wave_kernel<4>, dim3(ceil_div(B, 4)), dim3(256), 0, st, wb + pl.dOm, wf + pl.QKV, wf + pl.probs, wb + pl.dQKV, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
       case 2: hipLaunchKernelGGL(mha3_bwd_wave_kernel<2>, dim3(ceil_div(B, 4)), dim3(256), 0, st, wb + pl.dOm, wf + pl.QKV, wf + pl.probs, wb + pl.dQKV, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
       case 1: hipLaunchKernelGGL(mha3_bwd_wave_kernel<1>, dim3(ceil_div(B, 4)), dim3(256), 0, st, wb + pl.dOm, wf + pl.QKV, wf + pl.probs, wb + pl.dQKV, B, s->heads, mha3_hlog(s->heads), site(s, 3)); break;
@@ -367,7 +276,10 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* s
                            wb + pl.dQKV, B, E, s->heads, site(s, 3));
     }
     OCEAN_LAUNCH_CHECK();
-    OCEAN_TRY(lin_bwd(X, E, wb + pl.dQKV, 3 * E, 3 * B, 3 * E, E, P_[12], G_[12], G_[13], dX, E, 0, st));
+    {
+      const RcTokenMajor tokens;      // dQKV and dX are [B, 3, .]: three consecutive rows per sample
+      OCEAN_TRY(lin_bwd(X, E, wb + pl.dQKV, 3 * E, 3 * B, 3 * E, E, P_[12], G_[12], G_[13], dX, E, 0, st));
+    }
   } else {
     OCEAN_TRY(zero_f32(dX, 3 * BE, st));
   }
@@ -375,7 +287,13 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* s
   if (s->contrastive && dZp) {
     if (!Zp) return OCEAN_ERR_NULL;
     LinBwd l[3];
-    OCEAN_TRY(l2norm_bwd(dZp, Pd, Zp, Pd, wf + pl.nrm, wb + pl.dY2, Pd, 3 * B, Pd, 1e-12f, st));
+    if (rc_active()) {
+      for (int m = 0; m < 3; ++m)
+        OCEAN_TRY(l2norm_bwd(dZp + (size_t)m * B * Pd, Pd, Zp + (size_t)m * B * Pd, Pd, wf + pl.nrm + (size_t)m * B, wb + pl.dY2 + (size_t)m * B * Pd, Pd,
+                             B, Pd, 1e-12f, st));
+    } else {
+      OCEAN_TRY(l2norm_bwd(dZp, Pd, Zp, Pd, wf + pl.nrm, wb + pl.dY2, Pd, 3 * B, Pd, 1e-12f, st));
+    }
     for (int m = 0; m < 3; ++m)
       l[m] = LinBwd{wf + pl.Y1 + m * BE, E, wb + pl.dY2 + (size_t)m * B * Pd, Pd, B, Pd, E, P_[24 + 4 * m], G_[24 + 4 * m], G_[25 + 4 * m],
                     wb + pl.dY1 + m * BE, E};
@@ -394,12 +312,16 @@ int ocean_fusion_bwd(const ocean_fusion_shape* s, const float* t, const float* s
     ln[m] = LnBwdSet{dX + m * E, wf + pl.R + m * BE, wf + pl.lnsp + (size_t)m * 2 * B, P_[4 * m + 2], wb + pl.dR + m * BE, G_[4 * m + 2],
                      G_[4 * m + 3]};
   OCEAN_TRY(layernorm_bwd_batch(ln, 3, 3 * E, E, E, B, E, site(s, 0), st));
-  OCEAN_TRY(relu_bwd_inplace(wb + pl.dR, E, wf + pl.R, E, 3 * B, E, st));
+  if (rc_active()) {
+    for (int m = 0; m < 3; ++m) OCEAN_TRY(relu_bwd_inplace(wb + pl.dR + m * BE, E, wf + pl.R + m * BE, E, B, E, st));
+  } else {
+    OCEAN_TRY(relu_bwd_inplace(wb + pl.dR, E, wf + pl.R, E, 3 * B, E, st));
+  }
   LinBwd lb[3];
   for (int m = 0; m < 3; ++m)
     lb[m] = LinBwd{xin[m], xd[m], wb + pl.dR + m * BE, E, B, E, xd[m], P_[4 * m], G_[4 * m], G_[4 * m + 1], dxin[m], xd[m]};
   OCEAN_TRY(linear_bwd_batch(lb, 3, 0, st));
-  return OCEAN_OK;
+  return rc.finish();
 }
 
 // ---- one ProjectionHead called on its own: Linear -> ReLU -> Dropout -> Linear -> L2 normalise.

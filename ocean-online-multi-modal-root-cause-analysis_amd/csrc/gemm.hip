@@ -17,6 +17,7 @@
 // Global loads run two tiles ahead of the MFMAs through registers into a ring of
 // three LDS tiles, with one barrier per tile placed mid-tile (see the main loop).
 #include "gemm_epilogue.h"
+#include "rowchain.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -630,6 +631,19 @@ int ocean_launch_gemm_batch(const GemmP* ps, int n, hipStream_t stream) {
     if (ps[q].a_kmajor != ps[0].a_kmajor || ps[q].b_kn != ps[0].b_kn || ps[q].taps != ps[0].taps) return OCEAN_ERR_UNSUPPORTED;
     if (ps[q].a_kmajor && (ps[q].K != ps[0].K || ps[q].split_k != ps[0].split_k)) return OCEAN_ERR_UNSUPPORTED;
     b.g[q] = ps[q];
+  }
+  if (rc_collecting()) {
+    // a scope of rowchain.h is alive on this thread: row reductions join its batched launch, and - when a stage kernel
+    // is being recorded - the other problems become operations of its program; one that does not fit is launched as
+    // usual, in order
+    int taken = 0;
+    while (taken < n && rc_gemm(ps[taken], taken > 0)) ++taken;
+    if (taken == n) return OCEAN_OK;
+    if (taken > 0) {
+      int rest = OCEAN_OK;
+      for (int q = taken; q < n && rest == OCEAN_OK; ++q) rest = ocean_launch_gemm_batch(ps + q, 1, stream);
+      return rest;
+    }
   }
   for (int q = n; q < kGemmBatchMax; ++q) b.g[q] = ps[0];
   if (ocean_gemm_skinny_applies(b)) return ocean_launch_gemm_skinny(b, stream);

@@ -10,6 +10,7 @@
 // k and k+4 in one 32x32x2 MFMA on both operands alike - so there is no staging through LDS and every load of a wave's
 // slice can be in flight at once.
 #include "common.h"
+#include "rowchain.h"
 #include <cstdlib>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
@@ -436,6 +437,13 @@ static inline bool spans_overlap(const float* a, long rows_a, long ld_a, long co
 // layers: one launch of gemm_pair_kernel when both are work for the few-tile kernels and nothing one role writes is read
 // or written by the other; otherwise the two ordinary launches, weight gradients first.
 int ocean_launch_gemm_pair(const GemmP* w, int nw, const GemmP* d, int nd, hipStream_t stream) {
+  if (rc_collecting()) {
+    // a scope of rowchain.h is alive: the weight gradients join its batched reduction (and the data gradients the stage
+    // kernel, when one is being recorded) - through the ordinary batch launcher, which hands them over problem by problem
+    if (nw > 0) OCEAN_TRY(ocean_launch_gemm_batch(w, nw, stream));
+    if (nd > 0) OCEAN_TRY(ocean_launch_gemm_batch(d, nd, stream));
+    return OCEAN_OK;
+  }
   static const bool off = getenv("OCEAN_GEMM_NO_PAIR") != nullptr;         // measurement switch
   bool pair = !off && nw >= 1 && nd >= 1 && nw <= kGemmBatchMax && nd <= kGemmBatchMax;
   GemmBatch wb, db;

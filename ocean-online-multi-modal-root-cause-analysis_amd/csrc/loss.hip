@@ -9,6 +9,7 @@
 // two GEMMs (d a_hat = dL . x_hat, d x_hat = dL^T . a_hat).
 #include "../../include/ocean_hip.h"
 #include "ops.h"
+#include "rowchain.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
@@ -742,12 +743,15 @@ int ocean_head_fwd(const ocean_head_shape* s, const float* x, float* const* P_, 
   float* a1 = ws; float* a2 = ws + al4((size_t)s->B * s->h1);
   const DropoutP dr0 = head_site(s, 0), dr1 = head_site(s, 1);   // dropout rides in the epilogue of the producing GEMM
   Epi e0, e1; e0.drop = &dr0; e1.drop = &dr1;
+  RcScope rc(s->B, st);       // small batches: the three layers and the sigmoid are one launch (rowchain.h)
   OCEAN_TRY(linear_fwd(x, s->E, P_[0], P_[1], a1, s->h1, s->B, s->h1, s->E, 1, st, &e0));
   OCEAN_TRY(linear_fwd(a1, s->h1, P_[2], P_[3], a2, s->h2, s->B, s->h2, s->h1, 1, st, &e1));
   OCEAN_TRY(linear_fwd(a2, s->h2, P_[4], P_[5], logits, s->S, s->B, s->S, s->h2, 0, st));
-  hipLaunchKernelGGL(sigmoid_kernel, dim3(egrid((long)s->B * s->S)), dim3(256), 0, st, logits, probs, (long)s->B * s->S);
-  OCEAN_LAUNCH_CHECK();
-  return OCEAN_OK;
+  if (!rc_sigmoid(logits, probs, s->B, s->S)) {
+    hipLaunchKernelGGL(sigmoid_kernel, dim3(egrid((long)s->B * s->S)), dim3(256), 0, st, logits, probs, (long)s->B * s->S);
+    OCEAN_LAUNCH_CHECK();
+  }
+  return rc.finish();
 }
 
 int ocean_head_bwd(const ocean_head_shape* s, const float* x, float* const* P_, float* ws, float* wb, size_t wb_floats,
@@ -758,8 +762,11 @@ int ocean_head_bwd(const ocean_head_shape* s, const float* x, float* const* P_, 
   const int B = s->B;
   const float* a1 = ws; const float* a2 = ws + al4((size_t)B * s->h1);
   float* dl = wb; float* d1 = wb + al4((size_t)B * s->S); float* d2 = d1 + al4((size_t)B * s->h1);
-  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(egrid((long)B * s->S)), dim3(256), 0, st, dlogits, dprobs, probs, dl, (long)B * s->S);
-  OCEAN_LAUNCH_CHECK();
+  RcScope rc(B, st);
+  if (!rc_sigmoid_bwd(dlogits, dprobs, probs, dl, B, s->S)) {
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(egrid((long)B * s->S)), dim3(256), 0, st, dlogits, dprobs, probs, dl, (long)B * s->S);
+    OCEAN_LAUNCH_CHECK();
+  }
   const DropoutP dr0 = head_site(s, 0), dr1 = head_site(s, 1);
   Epi e0, e1;      // dropout and ReLU backward on the way out of the data gradients
   e0.drop = &dr0; e0.relu_mask = a1; e0.ld_mask = s->h1;
@@ -767,9 +774,9 @@ int ocean_head_bwd(const ocean_head_shape* s, const float* x, float* const* P_, 
   // per layer: weight gradient, bias gradient (column sums of the same operand) and data gradient
   OCEAN_TRY(linear_bwd_pair(a2, s->h2, dl, s->S, P_[4], G_[4], G_[5], d2, s->h2, B, s->S, s->h2, 0, st, &e1));
   OCEAN_TRY(linear_bwd_pair(a1, s->h1, d2, s->h2, P_[2], G_[2], G_[3], d1, s->h1, B, s->h2, s->h1, 0, st, &e0));
-  if (dx) return linear_bwd_pair(x, s->E, d1, s->h1, P_[0], G_[0], G_[1], dx, s->E, B, s->h1, s->E, 0, st);
-  OCEAN_TRY(linear_bwd_weight(d1, s->h1, x, s->E, G_[0], B, s->h1, s->E, st, G_[1]));
-  return OCEAN_OK;
+  if (dx) OCEAN_TRY(linear_bwd_pair(x, s->E, d1, s->h1, P_[0], G_[0], G_[1], dx, s->E, B, s->h1, s->E, 0, st));
+  else OCEAN_TRY(linear_bwd_weight(d1, s->h1, x, s->E, G_[0], B, s->h1, s->E, st, G_[1]));
+  return rc.finish();
 }
 
 // ---------------------------------------------------------------- Trainer's extra loss terms

@@ -10,6 +10,8 @@
 // and receive no gradient here (the reference gives them exact zeros).
 #include "../../include/ocean_hip.h"
 #include "ops.h"
+#include "rowbodies.h"
+#include "rowchain.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
@@ -22,32 +24,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr int kWaves = 4;
 
-// Nn: [3][B][W] LayerNormed modality vectors (t, s, l).  G[m] = pi_m * (n_m + w1 k1 + w2 k2) with
-// (k1,k2) = (s,l) for t, (t,l) for s, (t,s) for l and (w1,w2) = softmax([n_m.k1, n_m.k2]/sqrt(W)).
+// Nn: [3][B][W] LayerNormed modality vectors (t, s, l) -> G, cw (rowbody::cross_fwd_row), one wave per sample
 __global__ __launch_bounds__(256) void cross_fwd_kernel(const float* __restrict__ Nn, const float* __restrict__ mw,
                                                         float* __restrict__ G, float* __restrict__ cw, int B, int W) {
   const int lane = threadIdx.x & 63, b = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (b >= B) return;
-  const float* nt = Nn + (long)b * W;
-  const float* ns = Nn + ((long)B + b) * W;
-  const float* nl = Nn + (2L * B + b) * W;
-  float dts = 0.f, dtl = 0.f, dsl = 0.f;
-  for (int c = lane; c < W; c += 64) { const float t = nt[c], s = ns[c], l = nl[c]; dts += t * s; dtl += t * l; dsl += s * l; }
-  const float sc = 1.0f / sqrtf((float)W);
-  dts = wave_sum(dts) * sc; dtl = wave_sum(dtl) * sc; dsl = wave_sum(dsl) * sc;
-  auto sm2 = [](float a, float bb, float& w1, float& w2) { const float m = fmaxf(a, bb); const float ea = __expf(a - m), eb = __expf(bb - m); w1 = ea / (ea + eb); w2 = eb / (ea + eb); };
-  float wt1, wt2, ws1, ws2, wl1, wl2;
-  sm2(dts, dtl, wt1, wt2); sm2(dts, dsl, ws1, ws2); sm2(dtl, dsl, wl1, wl2);
-  const float m0 = mw[0], m1 = mw[1], m2 = mw[2], mm = fmaxf(m0, fmaxf(m1, m2));
-  const float e0 = __expf(m0 - mm), e1 = __expf(m1 - mm), e2 = __expf(m2 - mm), es = e0 + e1 + e2;
-  const float p0 = e0 / es, p1 = e1 / es, p2 = e2 / es;
-  for (int c = lane; c < W; c += 64) {
-    const float t = nt[c], s = ns[c], l = nl[c];
-    G[(long)b * W + c] = p0 * (t + wt1 * s + wt2 * l);
-    G[((long)B + b) * W + c] = p1 * (s + ws1 * t + ws2 * l);
-    G[(2L * B + b) * W + c] = p2 * (l + wl1 * t + wl2 * s);
-  }
-  if (lane == 0) { float* o = cw + (long)b * 6; o[0] = wt1; o[1] = wt2; o[2] = ws1; o[3] = ws2; o[4] = wl1; o[5] = wl2; }
+  rowbody::cross_fwd_row(Nn, W, (long)B * W, mw, G, W, (long)B * W, cw, W, b, lane);
 }
 
 __global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ Nn,
@@ -56,45 +38,7 @@ __global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict_
   __shared__ float red[kWaves][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x * kWaves + wave;
   float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f;
-  if (b < B) {
-    const float* nt = Nn + (long)b * W;
-    const float* ns = Nn + ((long)B + b) * W;
-    const float* nl = Nn + (2L * B + b) * W;
-    const float* gt = dG + (long)b * W;
-    const float* gs = dG + ((long)B + b) * W;
-    const float* gl = dG + (2L * B + b) * W;
-    const float* w = cw + (long)b * 6;
-    const float wt1 = w[0], wt2 = w[1], ws1 = w[2], ws2 = w[3], wl1 = w[4], wl2 = w[5];
-    const float m0 = mw[0], m1 = mw[1], m2 = mw[2], mm = fmaxf(m0, fmaxf(m1, m2));
-    const float e0 = __expf(m0 - mm), e1 = __expf(m1 - mm), e2 = __expf(m2 - mm), es = e0 + e1 + e2;
-    const float p0 = e0 / es, p1 = e1 / es, p2 = e2 / es;
-    // dots of de_m = pi_m * dg_m with each key, and dpi_m = dg_m . e_m
-    float at_s = 0.f, at_l = 0.f, as_t = 0.f, as_l = 0.f, al_t = 0.f, al_s = 0.f;
-    for (int c = lane; c < W; c += 64) {
-      const float t = nt[c], s = ns[c], l = nl[c], a = gt[c], bb = gs[c], cc = gl[c];
-      at_s += a * s; at_l += a * l; as_t += bb * t; as_l += bb * l; al_t += cc * t; al_s += cc * s;
-      dp0 += a * (t + wt1 * s + wt2 * l); dp1 += bb * (s + ws1 * t + ws2 * l); dp2 += cc * (l + wl1 * t + wl2 * s);
-    }
-    at_s = wave_sum(at_s) * p0; at_l = wave_sum(at_l) * p0; as_t = wave_sum(as_t) * p1; as_l = wave_sum(as_l) * p1;
-    al_t = wave_sum(al_t) * p2; al_s = wave_sum(al_s) * p2;
-    dp0 = wave_sum(dp0); dp1 = wave_sum(dp1); dp2 = wave_sum(dp2);
-    const float sc = 1.0f / sqrtf((float)W);
-    // softmax backward per modality: ds1 = w1*(dw1 - (w1 dw1 + w2 dw2)), scaled by 1/sqrt(W)
-    const float tt = wt1 * at_s + wt2 * at_l, dst1 = wt1 * (at_s - tt) * sc, dst2 = wt2 * (at_l - tt) * sc;
-    const float ss = ws1 * as_t + ws2 * as_l, dss1 = ws1 * (as_t - ss) * sc, dss2 = ws2 * (as_l - ss) * sc;
-    const float ll = wl1 * al_t + wl2 * al_s, dsl1 = wl1 * (al_t - ll) * sc, dsl2 = wl2 * (al_s - ll) * sc;
-    for (int c = lane; c < W; c += 64) {
-      const float t = nt[c], s = ns[c], l = nl[c];
-      const float a = gt[c] * p0, bb = gs[c] * p1, cc = gl[c] * p2;       // de_t, de_s, de_l
-      // t: query of its own block (keys s,l); key 1 of s's and l's blocks
-      const float dt = a + dst1 * s + dst2 * l + ws1 * bb + dss1 * s + wl1 * cc + dsl1 * l;
-      // s: query (keys t,l); key 1 of t's block, key 2 of l's block
-      const float ds = bb + dss1 * t + dss2 * l + wt1 * a + dst1 * t + wl2 * cc + dsl2 * l;
-      // l: query (keys t,s); key 2 of t's and s's blocks
-      const float dl = cc + dsl1 * t + dsl2 * s + wt2 * a + dst2 * t + ws2 * bb + dss2 * s;
-      dN[(long)b * W + c] = dt; dN[((long)B + b) * W + c] = ds; dN[(2L * B + b) * W + c] = dl;
-    }
-  }
+  if (b < B) rowbody::cross_bwd_row(dG, W, (long)B * W, Nn, W, (long)B * W, cw, mw, dN, W, (long)B * W, W, b, lane, dp0, dp1, dp2);
   if (lane == 0) { red[wave][0] = dp0; red[wave][1] = dp1; red[wave][2] = dp2; }
   __syncthreads();
   if (threadIdx.x < 3) {
@@ -114,45 +58,28 @@ __global__ void modality_bwd_kernel(const float* __restrict__ dpi, const float* 
   for (int i = 0; i < 3; ++i) dmw[i] += p[i] * (dpi[i] - dot);
 }
 
-// rows r in [0,3B): i = sigmoid(hid[r].w2 + b2);  cat[b, m*W + c] = G[r,c] * i   (r = m*B + b)
+// rows r in [0,3B): the sigmoid feature gate (rowbody::gate_fwd_row / gate_bwd_row), one wave per row
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ hid, const float* __restrict__ w2,
                                                        const float* __restrict__ b2, const float* __restrict__ G,
                                                        float* __restrict__ ig, float* __restrict__ cat, int B, int W, int Wh) {
   const int lane = threadIdx.x & 63, r = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (r >= 3 * B) return;
-  float z = 0.f;
-  for (int k = lane; k < Wh; k += 64) z += hid[(long)r * Wh + k] * w2[k];
-  z = wave_sum(z) + b2[0];
-  const float i = 1.0f / (1.0f + __expf(-z));
-  const int m = r / B, b = r % B;
-  for (int c = lane; c < W; c += 64) cat[(long)b * 3 * W + m * W + c] = G[(long)r * W + c] * i;
-  if (lane == 0) ig[r] = i;
+  rowbody::gate_fwd_row(hid, Wh, (long)B * Wh, w2, b2, G, W, (long)B * W, ig, cat, 3 * W, B, W, Wh, r / B, r % B, lane);
 }
 
-// dG = dcat * i;  dz = (dcat . G) * i(1-i);  dhid = dz * w2 where hid > 0
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dcat, const float* __restrict__ G,
                                                        const float* __restrict__ ig, const float* __restrict__ hid,
                                                        const float* __restrict__ w2, float* __restrict__ dG,
                                                        float* __restrict__ dz, float* __restrict__ dhid, int B, int W, int Wh) {
   const int lane = threadIdx.x & 63, r = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (r >= 3 * B) return;
-  const int m = r / B, b = r % B;
-  const float i = ig[r];
-  float d = 0.f;
-  for (int c = lane; c < W; c += 64) {
-    const float g = dcat[(long)b * 3 * W + m * W + c];
-    d += g * G[(long)r * W + c];
-    dG[(long)r * W + c] = g * i;
-  }
-  d = wave_sum(d) * i * (1.0f - i);
-  for (int k = lane; k < Wh; k += 64) dhid[(long)r * Wh + k] = hid[(long)r * Wh + k] > 0.f ? d * w2[k] : 0.f;
-  if (lane == 0) dz[r] = d;
+  rowbody::gate_bwd_row(dcat, 3 * W, G, W, (long)B * W, ig, hid, Wh, (long)B * Wh, w2, dG, W, (long)B * W, dz, dhid, Wh, (long)B * Wh, B, W, Wh, r / B, r % B, lane);
 }
 
 struct MfaPlan {
   int B, W, Wh;
   size_t P, V, A, lnst, Nn, cw, G, Hd, ig, cat, F, O1, O2, lnso, fwd_total;
-  size_t d1, d2, dHd, dz, dcat, e1, e2, dpi, bwd_total;
+  size_t d1, d2, d3, d4, dHd, dz, dcat, e1, e2, e3, dpi, bwd_total;
 };
 inline size_t al4(size_t x) { return (x + 3) & ~size_t(3); }
 
@@ -172,6 +99,9 @@ int make_plan(const ocean_mfa_shape* s, MfaPlan* p) {
   o = 0;
   p->d1 = take(3 * B * W); p->d2 = take(3 * B * W); p->dHd = take(3 * B * Wh); p->dz = take(3 * B); p->dcat = take(3 * B * W);
   p->e1 = take(B * W); p->e2 = take(B * W); p->dpi = take(4);
+  // a layer's output gradient stays untouched until the end of the pass (the weight gradients of a small batch are all
+  // formed there, in one launch: rowchain.h), so no two layers share a gradient buffer
+  p->e3 = take(B * W); p->d3 = take(3 * B * W); p->d4 = take(3 * B * W);
   p->bwd_total = o;
   return OCEAN_OK;
 }
@@ -213,6 +143,7 @@ int ocean_mfa_fwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
   const float* xin[3] = {t, sp, lg};
   const int xd[3] = {s->td, s->sd, s->ld};
   const DropoutP none = {0.f, 0, nullptr};
+  RcScope rc(B, st);       // small batches: the whole chain below becomes one launch (rowchain.h)
   // the three modality branches run as one launch per layer; dropout sites cover all three (contiguous [3, B, W])
   LinFwd l[3];
   for (int m = 0; m < 3; ++m) l[m] = LinFwd{xin[m], xd[m], P_[2 * m], P_[2 * m + 1], ws + pl.P + m * BW, W, B, W, xd[m]};
@@ -226,18 +157,28 @@ int ocean_mfa_fwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
   for (int m = 0; m < 3; ++m)
     ln[m] = LnFwdSet{ws + pl.A + m * BW, P_[18 + 2 * m], P_[19 + 2 * m], ws + pl.Nn + m * BW, ws + pl.lnst + (size_t)m * 2 * B};
   OCEAN_TRY(layernorm_fwd_batch(ln, 3, W, W, B, W, s->eps, site(s, 3), st));   // A stays as computed; the LayerNorm drops its input
-  hipLaunchKernelGGL(cross_fwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.Nn, P_[26], ws + pl.G, ws + pl.cw, B, W);
-  OCEAN_LAUNCH_CHECK();
-  OCEAN_TRY(linear_fwd(ws + pl.G, W, P_[27], P_[28], ws + pl.Hd, Wh, 3 * B, Wh, W, 1, st));
-  hipLaunchKernelGGL(gate_fwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, ws + pl.Hd, P_[29], P_[30], ws + pl.G, ws + pl.ig,
-                     ws + pl.cat, B, W, Wh);
-  OCEAN_LAUNCH_CHECK();
+  if (!rc_cross_fwd(ws + pl.Nn, P_[26], ws + pl.G, ws + pl.cw, B, W)) {
+    hipLaunchKernelGGL(cross_fwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, ws + pl.Nn, P_[26], ws + pl.G, ws + pl.cw, B, W);
+    OCEAN_LAUNCH_CHECK();
+  }
+  if (rc_active()) {
+    // the stage kernel walks samples: the [3][B][.] stack is three matrices of one row per sample
+    for (int m = 0; m < 3; ++m) l[m] = LinFwd{ws + pl.G + m * BW, W, P_[27], P_[28], ws + pl.Hd + (size_t)m * B * Wh, Wh, B, Wh, W};
+    OCEAN_TRY(linear_fwd_batch(l, 3, 1, st));
+  } else {
+    OCEAN_TRY(linear_fwd(ws + pl.G, W, P_[27], P_[28], ws + pl.Hd, Wh, 3 * B, Wh, W, 1, st));
+  }
+  if (!rc_gate_fwd(ws + pl.Hd, P_[29], P_[30], ws + pl.G, ws + pl.ig, ws + pl.cat, B, W, Wh)) {
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, ws + pl.Hd, P_[29], P_[30], ws + pl.G, ws + pl.ig,
+                       ws + pl.cat, B, W, Wh);
+    OCEAN_LAUNCH_CHECK();
+  }
   OCEAN_TRY(linear_fwd(ws + pl.cat, 3 * W, P_[31], P_[32], ws + pl.F, W, B, W, 3 * W, 0, st));
   Epi e6; e6.drop = &d6;
   OCEAN_TRY(linear_fwd(ws + pl.F, W, P_[33], P_[34], ws + pl.O1, W, B, W, W, 1, st, &e6));
   OCEAN_TRY(linear_fwd(ws + pl.O1, W, P_[35], P_[36], ws + pl.O2, W, B, W, W, 0, st));
   OCEAN_TRY(layernorm_fwd(ws + pl.O2, W, P_[24], P_[25], out, W, ws + pl.lnso, B, W, s->eps, none, st));
-  return OCEAN_OK;
+  return rc.finish();
 }
 
 int ocean_mfa_bwd(const ocean_mfa_shape* s, const float* t, const float* sp, const float* lg, float* const* P_, float* wf,
@@ -250,26 +191,41 @@ int ocean_mfa_bwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
   const int B = s->B, W = s->W, Wh = pl.Wh;
   const size_t BW = (size_t)B * W;
   const DropoutP none = {0.f, 0, nullptr};
-  float* e1 = wb + pl.e1; float* e2 = wb + pl.e2; float* d1 = wb + pl.d1; float* d2 = wb + pl.d2;
+  float* e1 = wb + pl.e1; float* e2 = wb + pl.e2; float* e3 = wb + pl.e3;
+  float* d1 = wb + pl.d1; float* d2 = wb + pl.d2; float* d3 = wb + pl.d3; float* d4 = wb + pl.d4;
+  // the accumulator of d(pi) is cleared first: with a small batch everything below up to the weight gradients is ONE
+  // launch (rowchain.h), and nothing of it may sit in front of this fill
+  OCEAN_TRY(zero_f32(wb + pl.dpi, 4, st));
+  RcScope rc(B, st);
   // output LayerNorm and MLP
   OCEAN_TRY(layernorm_bwd(dout, W, wf + pl.O2, W, wf + pl.lnso, P_[24], e1, W, G_[24], G_[25], B, W, none, st));
   const DropoutP d0 = site(s, 0), d6 = site(s, 6);
   Epi e6; e6.drop = &d6; e6.relu_mask = wf + pl.O1; e6.ld_mask = W;     // dropout and ReLU backward on the way out of the dgrad GEMM
   OCEAN_TRY(lin_bwd(wf + pl.O1, W, e1, W, B, W, W, P_[35], G_[35], G_[36], e2, W, 0, st, &e6));
-  OCEAN_TRY(lin_bwd(wf + pl.F, W, e2, W, B, W, W, P_[33], G_[33], G_[34], e1, W, 0, st));
-  OCEAN_TRY(lin_bwd(wf + pl.cat, 3 * W, e1, W, B, W, 3 * W, P_[31], G_[31], G_[32], wb + pl.dcat, 3 * W, 0, st));
+  OCEAN_TRY(lin_bwd(wf + pl.F, W, e2, W, B, W, W, P_[33], G_[33], G_[34], e3, W, 0, st));
+  OCEAN_TRY(lin_bwd(wf + pl.cat, 3 * W, e3, W, B, W, 3 * W, P_[31], G_[31], G_[32], wb + pl.dcat, 3 * W, 0, st));
   // feature gate
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, wb + pl.dcat, wf + pl.G, wf + pl.ig, wf + pl.Hd,
-                     P_[29], d1, wb + pl.dz, wb + pl.dHd, B, W, Wh);
-  OCEAN_LAUNCH_CHECK();
+  if (!rc_gate_bwd(wb + pl.dcat, wf + pl.G, wf + pl.ig, wf + pl.Hd, P_[29], d1, wb + pl.dz, wb + pl.dHd, B, W, Wh)) {
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(3 * B, kWaves)), dim3(256), 0, st, wb + pl.dcat, wf + pl.G, wf + pl.ig, wf + pl.Hd,
+                       P_[29], d1, wb + pl.dz, wb + pl.dHd, B, W, Wh);
+    OCEAN_LAUNCH_CHECK();
+  }
   OCEAN_TRY(lin_bwd(wf + pl.Hd, Wh, wb + pl.dz, 1, 3 * B, 1, Wh, P_[29], G_[29], G_[30], nullptr, 0, 0, st));
-  OCEAN_TRY(lin_bwd(wf + pl.G, W, wb + pl.dHd, Wh, 3 * B, Wh, W, P_[27], G_[27], G_[28], d1, W, 1, st));
+  if (rc_active()) {
+    // weight gradient over all 3 B rows; the data gradient per modality (one row per sample each)
+    OCEAN_TRY(linear_bwd_weight(wb + pl.dHd, Wh, wf + pl.G, W, G_[27], 3 * B, Wh, W, st, G_[28]));
+    LinBwd g3[3];
+    for (int m = 0; m < 3; ++m)
+      g3[m] = LinBwd{wf + pl.G + m * BW, W, wb + pl.dHd + (size_t)m * B * Wh, Wh, B, Wh, W, P_[27], nullptr, nullptr, d1 + m * BW, W};
+    OCEAN_TRY(linear_bwd_batch(g3, 3, 1, st));
+  } else {
+    OCEAN_TRY(lin_bwd(wf + pl.G, W, wb + pl.dHd, Wh, 3 * B, Wh, W, P_[27], G_[27], G_[28], d1, W, 1, st));
+  }
   // cross-modal softmax and modality weights
-  OCEAN_TRY(zero_f32(wb + pl.dpi, 4, st));
-  hipLaunchKernelGGL(cross_bwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, d1, wf + pl.Nn, wf + pl.cw, P_[26], d2, wb + pl.dpi, B, W);
-  OCEAN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(modality_bwd_kernel, dim3(1), dim3(64), 0, st, wb + pl.dpi, P_[26], G_[26]);
-  OCEAN_LAUNCH_CHECK();
+  if (!rc_cross_bwd(d1, wf + pl.Nn, wf + pl.cw, P_[26], d2, wb + pl.dpi, B, W)) {
+    hipLaunchKernelGGL(cross_bwd_kernel, dim3(ceil_div(B, kWaves)), dim3(256), 0, st, d1, wf + pl.Nn, wf + pl.cw, P_[26], d2, wb + pl.dpi, B, W);
+    OCEAN_LAUNCH_CHECK();
+  }
   const float* xin[3] = {t, sp, lg};
   const int xd[3] = {s->td, s->sd, s->ld};
   float* dxin[3] = {dt, dsp, dlg};
@@ -280,14 +236,18 @@ int ocean_mfa_bwd(const ocean_mfa_shape* s, const float* t, const float* sp, con
   OCEAN_TRY(layernorm_bwd_batch(ln, 3, W, W, W, B, W, site(s, 3), st));
   LinBwd l[3];
   for (int m = 0; m < 3; ++m)
-    l[m] = LinBwd{wf + pl.V + m * BW, W, d2 + m * BW, W, B, W, W, P_[8 + 4 * m], G_[8 + 4 * m], G_[9 + 4 * m], d1 + m * BW, W};
+    l[m] = LinBwd{wf + pl.V + m * BW, W, d2 + m * BW, W, B, W, W, P_[8 + 4 * m], G_[8 + 4 * m], G_[9 + 4 * m], d3 + m * BW, W};
   OCEAN_TRY(linear_bwd_batch(l, 3, 0, st, &d0, W / s->heads));
   for (int m = 0; m < 3; ++m)
-    l[m] = LinBwd{wf + pl.P + m * BW, W, d1 + m * BW, W, B, W, W, P_[6 + 4 * m], G_[6 + 4 * m], G_[7 + 4 * m], d2 + m * BW, W};
+    l[m] = LinBwd{wf + pl.P + m * BW, W, d3 + m * BW, W, B, W, W, P_[6 + 4 * m], G_[6 + 4 * m], G_[7 + 4 * m], d4 + m * BW, W};
   OCEAN_TRY(linear_bwd_batch(l, 3, 0, st));
   for (int m = 0; m < 3; ++m)
-    l[m] = LinBwd{xin[m], xd[m], d2 + m * BW, W, B, W, xd[m], P_[2 * m], G_[2 * m], G_[2 * m + 1], dxin[m], xd[m]};
+    l[m] = LinBwd{xin[m], xd[m], d4 + m * BW, W, B, W, xd[m], P_[2 * m], G_[2 * m], G_[2 * m + 1], dxin[m], xd[m]};
   OCEAN_TRY(linear_bwd_batch(l, 3, 0, st));
+  OCEAN_TRY(rc.finish());
+  // d(modality_weights) needs every sample's term of d(pi): after the chain
+  hipLaunchKernelGGL(modality_bwd_kernel, dim3(1), dim3(64), 0, st, wb + pl.dpi, P_[26], G_[26]);
+  OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }
 

@@ -1,6 +1,7 @@
 // Small shared device routines: linear-layer wrappers over the MFMA GEMM,
 // column sums, ReLU backward, fills and strided copies.
 #include "ops.h"
+#include "rowchain.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 static void apply_epi(GemmP& p, const Epi* e) {
@@ -182,6 +183,12 @@ inline int grid_for(long n, int block = 256, int cap = 4096) {
 
 int colsum_add_batch(const ColSum* c, int n, hipStream_t s) {
   if (n < 1 || n > kGemmBatchMax) return OCEAN_ERR_BAD_SHAPE;
+  if (rc_collecting()) {
+    int taken = 0;
+    while (taken < n && rc_colsum(c[taken].a, c[taken].lda, c[taken].M, c[taken].N, c[taken].out)) ++taken;
+    if (taken == n) return OCEAN_OK;
+    c += taken; n -= taken;
+  }
   ColSumBatch b;
   bool v4 = true;
   int M = 0, N = 0;
@@ -215,6 +222,7 @@ int colsum_add(const float* a, int lda, int M, int N, float* out, hipStream_t s)
 }
 
 int relu_bwd_inplace(float* dy, int lddy, const float* y, int ldy, int M, int N, hipStream_t s) {
+  if (rc_active() && rc_relu_bwd(dy, lddy, y, ldy, M, N, false)) return OCEAN_OK;
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, s, dy, lddy, y, ldy, M, N);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
@@ -222,6 +230,7 @@ int relu_bwd_inplace(float* dy, int lddy, const float* y, int ldy, int M, int N,
 
 int zero_f32(float* dst, size_t n, hipStream_t s) {
   if (n == 0) return OCEAN_OK;
+  rc_flush();
   hipLaunchKernelGGL(fill_zero_kernel<float>, dim3(grid_for((long)n)), dim3(256), 0, s, dst, n);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
@@ -229,12 +238,14 @@ int zero_f32(float* dst, size_t n, hipStream_t s) {
 
 int zero_f64(double* dst, size_t n, hipStream_t s) {
   if (n == 0) return OCEAN_OK;
+  rc_flush();
   hipLaunchKernelGGL(fill_zero_kernel<double>, dim3(grid_for((long)n)), dim3(256), 0, s, dst, n);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
 }
 
 int copy2d(float* dst, int ldd, const float* src, int lds, int M, int N, int accumulate, hipStream_t s) {
+  if (rc_active() && rc_copy2d(dst, ldd, src, lds, M, N, accumulate)) return OCEAN_OK;
   hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, s, dst, ldd, src, lds, M, N, accumulate);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;

@@ -3,6 +3,8 @@
 // stride the row (coalesced), reductions by wavefront shuffles; rows are
 // re-read from L1 rather than cached in registers so any width works.
 #include "ops.h"
+#include "rowbodies.h"
+#include "rowchain.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
@@ -28,23 +30,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnFwdBatch batch, int
   float* __restrict__ stats = st.stats;
   const int lane = threadIdx.x & 63, row = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* xr = x + (long)row * ldx;
-  const uint64_t drow = (uint64_t)blockIdx.y * rows + row;
-  auto val = [&](int c) { float v = xr[c]; if (dp.p > 0.f) v *= dropout_keep(dp, drow * W + c); return v; };
-  float s = 0.f;
-  for (int c = lane; c < W; c += 64) s += val(c);
-  const float mean = wave_sum(s) / (float)W;
-  float q = 0.f;
-  for (int c = lane; c < W; c += 64) { const float d = val(c) - mean; q += d * d; }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)W + eps);
-  for (int c = lane; c < W; c += 64) y[(long)row * ldy + c] = (val(c) - mean) * rstd * gamma[c] + beta[c];
-  if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  rowbody::ln_fwd_row(x, ldx, gamma, beta, y, ldy, stats, row, (uint64_t)blockIdx.y * rows + row, W, eps, dp, lane);
 }
 
 // Each wave walks rows row0 + w, row0 + w + kWaves, ... of its block's chunk so the
 // per-column gamma/beta partial sums stay in registers (up to 16 columns per lane).
 constexpr int kLnRowsPerBlock = 8;    // two rows per wave: a wave works through its rows one dependent round trip after the other
-constexpr int kMaxColsPerLane = 16;
+constexpr int kMaxColsPerLane = rowbody::kMaxColsPerLane;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdBatch batch, int lddy, int ldx, int lddx, int rows, int W, DropoutP dp) {
   dp = dropout_resolve(dp);
   const LnBwdSet& st = batch.s[blockIdx.y];
@@ -61,35 +53,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdBatch batch, int
 #pragma unroll
   for (int k = 0; k < kMaxColsPerLane; ++k) { pg[k] = 0.f; pb[k] = 0.f; }
   const int r0 = blockIdx.x * kLnRowsPerBlock, r1 = min(rows, r0 + kLnRowsPerBlock);
-  for (int row = r0 + wave; row < r1; row += kWaves) {
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    const float* xr = x + (long)row * ldx;
-    const float* gr = dy + (long)row * lddy;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < kMaxColsPerLane; ++k) {
-      const int c = lane + 64 * k;
-      if (c < W) {
-        float xv = xr[c];
-        if (dp.p > 0.f) xv *= dropout_keep(dp, (drow0 + row) * W + c);
-        const float xh = (xv - mean) * rstd, g = gr[c];
-        pg[k] += g * xh; pb[k] += g;
-        const float dxh = g * gamma[c];
-        s1 += dxh; s2 += dxh * xh;
-      }
-    }
-    s1 = wave_sum(s1) / (float)W; s2 = wave_sum(s2) / (float)W;
-#pragma unroll
-    for (int k = 0; k < kMaxColsPerLane; ++k) {
-      const int c = lane + 64 * k;
-      if (c < W) {
-        float keep = 1.f, xv = xr[c];
-        if (dp.p > 0.f) { keep = dropout_keep(dp, (drow0 + row) * W + c); xv *= keep; }
-        const float xh = (xv - mean) * rstd;
-        dx[(long)row * lddx + c] = rstd * (gr[c] * gamma[c] - s1 - xh * s2) * keep;
-      }
-    }
-  }
+  for (int row = r0 + wave; row < r1; row += kWaves)
+    rowbody::ln_bwd_row(dy, lddy, x, ldx, stats, gamma, dx, lddx, row, drow0 + row, W, dp, lane, pg, pb);
   __shared__ float red[2][kWaves][64 * kMaxColsPerLane];
 #pragma unroll
   for (int k = 0; k < kMaxColsPerLane; ++k) {
@@ -110,13 +75,7 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
                                                          float* __restrict__ norms, int rows, int W, float eps) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* xr = x + (long)row * ldx;
-  float q = 0.f;
-  for (int c = lane; c < W; c += 64) q += xr[c] * xr[c];
-  const float nrm = sqrtf(wave_sum(q));
-  const float inv = 1.0f / fmaxf(nrm, eps);
-  for (int c = lane; c < W; c += 64) y[(long)row * ldy + c] = xr[c] * inv;
-  if (lane == 0) norms[row] = nrm;
+  rowbody::l2norm_fwd_row(x, ldx, y, ldy, norms, row, W, eps, lane);
 }
 
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
@@ -124,16 +83,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
                                                          int rows, int W, float eps) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * kWaves + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const float* gr = dy + (long)row * lddy;
-  const float* yr = y + (long)row * ldy;
-  float d = 0.f;
-  for (int c = lane; c < W; c += 64) d += gr[c] * yr[c];
-  d = wave_sum(d);
-  const float nrm = norms[row];
-  // below eps the forward is x/eps (linear): no projection term
-  const float inv = 1.0f / fmaxf(nrm, eps);
-  const float proj = nrm > eps ? d : 0.f;
-  for (int c = lane; c < W; c += 64) dx[(long)row * lddx + c] = (gr[c] - yr[c] * proj) * inv;
+  rowbody::l2norm_bwd_row(dy, lddy, y, ldy, norms, dx, lddx, row, W, eps, lane);
 }
 
 __global__ void dropout_kernel(float* __restrict__ x, int ld, int M, int N, int group, DropoutP d) {
@@ -186,6 +136,14 @@ __global__ __launch_bounds__(256) void mean_mid_kernel2(const float* __restrict_
 
 int layernorm_fwd_batch(const LnFwdSet* sets, int n, int ldx, int ldy, int rows, int W, float eps, DropoutP in_drop, hipStream_t s) {
   if (rows <= 0 || W <= 0 || n < 1 || n > kLnSets) return OCEAN_ERR_BAD_SHAPE;
+  if (rc_active()) {
+    // a stage kernel is being assembled (rowchain.h): one operation per set, numbered in the dropout site as here
+    int taken = 0;
+    while (taken < n && rc_ln_fwd(sets[taken].x, ldx, sets[taken].gamma, sets[taken].beta, sets[taken].y, ldy, sets[taken].stats, rows, W, eps,
+                                  in_drop, taken * rows, taken > 0)) ++taken;
+    if (taken == n) return OCEAN_OK;
+    if (taken > 0) return OCEAN_ERR_UNSUPPORTED;     // (every set of a batch has the same shape: the first one decides)
+  }
   LnFwdBatch b;
   for (int q = 0; q < kLnSets; ++q) b.s[q] = sets[q < n ? q : 0];
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(rows, kWaves), n), dim3(256), 0, s, b, ldx, ldy, rows, W, eps, in_drop);
@@ -203,6 +161,13 @@ int layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta
 int layernorm_bwd_batch(const LnBwdSet* sets, int n, int lddy, int ldx, int lddx, int rows, int W, DropoutP in_drop, hipStream_t s) {
   if (rows <= 0 || W <= 0 || n < 1 || n > kLnSets) return OCEAN_ERR_BAD_SHAPE;
   if (W > 64 * kMaxColsPerLane) return OCEAN_ERR_UNSUPPORTED;
+  if (rc_active()) {
+    int taken = 0;
+    while (taken < n && rc_ln_bwd(sets[taken].dy, lddy, sets[taken].x, ldx, sets[taken].stats, sets[taken].gamma, sets[taken].dx, lddx,
+                                  sets[taken].dgamma, sets[taken].dbeta, rows, W, in_drop, taken * rows, taken > 0)) ++taken;
+    if (taken == n) return OCEAN_OK;
+    if (taken > 0) return OCEAN_ERR_UNSUPPORTED;
+  }
   LnBwdBatch b;
   for (int q = 0; q < kLnSets; ++q) b.s[q] = sets[q < n ? q : 0];
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(rows, kLnRowsPerBlock), n), dim3(256), 0, s, b, lddy, ldx, lddx, rows, W, in_drop);
@@ -218,6 +183,7 @@ int layernorm_bwd(const float* dy, int lddy, const float* x, int ldx, const floa
 }
 
 int l2norm_fwd(const float* x, int ldx, float* y, int ldy, float* norms, int rows, int W, float eps, hipStream_t s) {
+  if (rc_active() && rc_l2norm_fwd(x, ldx, y, ldy, norms, rows, W, eps, false)) return OCEAN_OK;
   hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(ceil_div(rows, kWaves)), dim3(256), 0, s, x, ldx, y, ldy, norms, rows, W, eps);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
@@ -225,6 +191,7 @@ int l2norm_fwd(const float* x, int ldx, float* y, int ldy, float* norms, int row
 
 int l2norm_bwd(const float* dy, int lddy, const float* y, int ldy, const float* norms, float* dx, int lddx,
                int rows, int W, float eps, hipStream_t s) {
+  if (rc_active() && rc_l2norm_bwd(dy, lddy, y, ldy, norms, dx, lddx, rows, W, eps, false)) return OCEAN_OK;
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(ceil_div(rows, kWaves)), dim3(256), 0, s, dy, lddy, y, ldy, norms, dx, lddx, rows, W, eps);
   OCEAN_LAUNCH_CHECK();
   return OCEAN_OK;
@@ -232,6 +199,7 @@ int l2norm_bwd(const float* dy, int lddy, const float* y, int ldy, const float* 
 
 int dropout_inplace(float* x, int ld, int M, int N, int group, DropoutP d, hipStream_t s) {
   if (d.p <= 0.f) return OCEAN_OK;
+  rc_flush();
   long g = ((long)M * N + 255) / 256;
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(dropout_kernel, dim3((int)g), dim3(256), 0, s, x, ld, M, N, group, d);
@@ -240,6 +208,7 @@ int dropout_inplace(float* x, int ld, int M, int N, int group, DropoutP d, hipSt
 }
 
 int mean_mid(const float* a, float* out, int G, int n, int C, hipStream_t s) {
+  if (rc_active() && rc_mean_mid(a, out, G, n, C)) return OCEAN_OK;
   const bool v4 = C % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0;
   const int cg = v4 ? C / 4 : C;
   int wlog = 0;

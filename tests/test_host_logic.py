@@ -242,17 +242,47 @@ def test_bench_rank_launcher_stops_the_other_ranks_when_one_fails(monkeypatch):
     real = subprocess.Popen
     seen = []
 
-    def stand_in(cmd, env=None):
+    def stand_in(cmd, env=None, stderr=None):
         rank = int(env["RANK"])
         seen.append((rank, env["WORLD_SIZE"], env["MASTER_ADDR"]))
-        code = "import sys; sys.exit(3)" if rank == 1 else "import time; time.sleep(60)"
-        return real([sys.executable, "-c", code])
+        code = "import sys; print('rank one broke', file=sys.stderr); sys.exit(3)" if rank == 1 else "import time; time.sleep(60)"
+        return real([sys.executable, "-c", code], stderr=stderr)
 
     monkeypatch.setattr(subprocess, "Popen", stand_in)
     t0 = time.time()
     assert bench.launch_ranks(3, []) == 3
     assert time.time() - t0 < 20
     assert sorted(seen) == [(0, "3", "127.0.0.1"), (1, "3", "127.0.0.1"), (2, "3", "127.0.0.1")]
+
+
+def test_bench_rank_launcher_names_the_hung_ranks_at_its_wall_clock_limit(monkeypatch, tmp_path, capfd):
+    """Ranks that never finish (a collective some rank never entered): after OCEAN_BENCH_TIMEOUT seconds the launcher ends
+    them, exits with 124 and says which ranks were still running; every rank's stderr is in its own file."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    monkeypatch.setenv("OCEAN_BENCH_TIMEOUT", "2")
+    monkeypatch.setenv("OCEAN_BENCH_LOG_DIR", str(tmp_path))
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    real = subprocess.Popen
+
+    def stand_in(cmd, env=None, stderr=None):
+        code = f"import sys, time; print('rank {env['RANK']} waiting', file=sys.stderr, flush=True); time.sleep(60)"
+        return real([sys.executable, "-c", code], stderr=stderr)
+
+    monkeypatch.setattr(subprocess, "Popen", stand_in)
+    t0 = time.time()
+    assert bench.launch_ranks(2, []) == 124
+    assert time.time() - t0 < 20
+    err = capfd.readouterr().err
+    assert "ranks still running: [0, 1]" in err and "rank 1 waiting" in err
+    assert sorted(os.listdir(tmp_path)) == ["rank0.err", "rank1.err"]
 
 
 def test_model_copies_do_not_carry_device_caches():
