@@ -37,7 +37,9 @@ __device__ __forceinline__ EpiArgs make_epi_args(const GemmP& p) {
 // element costs its arithmetic and one store and nothing else.  acc register r of lane l holds
 // C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] of its 32x32 tile; the four waves sit 2 x 2 over the block tile.
 // ATOMIC: the output accumulates (row reductions).  BNS: the BatchNorm-backward column sums described at GemmP::bn_u.
-template <int BM, int BN, bool ATOMIC, bool BNS, int TM, int TN>
+// RBROWS (with BNS): a broadcast residual (r_bcast_T > 0) is looked up per output row, R[row / r_bcast_T], for tiles
+// that straddle samples; without it the row is taken to be the same for the whole tile.
+template <int BM, int BN, bool ATOMIC, bool BNS, bool RBROWS = false, int TM, int TN>
 __device__ __forceinline__ void epilogue_full(f32x16 (&acc)[TM][TN], const EpiArgs& e, float* Cz, const DropoutP bn_drop,
                                               const int m0, const int n0, const int tile_m, const int wave, const int lane) {
   constexpr int WN = 2;
@@ -68,6 +70,14 @@ __device__ __forceinline__ void epilogue_full(f32x16 (&acc)[TM][TN], const EpiAr
     // fetched up front for the same reason.  (By now the main loop's staging and fragment registers are free.)
     constexpr int G = 16, GPS = 16 / G, NG = TN * TM * GPS;
     const bool bcast_r = has_r && e.r_bcast_T > 0;
+    // row / r_bcast_T for rows below 2^24: the fp32 quotient is off by one at most, and is put right
+    const float rcp_T = bcast_r ? 1.0f / (float)e.r_bcast_T : 0.f;
+    auto sample_of = [&](uint32_t row) {
+      uint32_t q = (uint32_t)((float)row * rcp_T);
+      const int rem = (int)(row - q * (uint32_t)e.r_bcast_T);
+      if (rem < 0) --q; else if (rem >= e.r_bcast_T) ++q;
+      return q;
+    };
     float sc_[TN], sh_[TN], mu_[TN], is_[TN], rb_[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -75,7 +85,7 @@ __device__ __forceinline__ void epilogue_full(f32x16 (&acc)[TM][TN], const EpiAr
       sc_[j] = e.bn_scale[c]; sh_[j] = e.bn_shift[c]; mu_[j] = e.bn_mean[c]; is_[j] = e.bn_invstd[c];
       // residual broadcast from one row per sample: the host sends such a launch here only when a tile lies inside one
       // sample (T % BM == 0), so the row is block-uniform and the value depends on the column alone
-      rb_[j] = bcast_r ? e.r_scale * e.R[(long)(m0 / e.r_bcast_T) * e.ldr + c] : 0.f;
+      rb_[j] = (bcast_r && !RBROWS) ? e.r_scale * e.R[(long)(m0 / e.r_bcast_T) * e.ldr + c] : 0.f;
     }
     float rv[2][G], uv[2][G];
     auto issue = [&](const int gi, const int buf) {
@@ -84,7 +94,8 @@ __device__ __forceinline__ void epilogue_full(f32x16 (&acc)[TM][TN], const EpiAr
       for (int x = 0; x < G; ++x) {
         const int r = r0 + x;
         const uint32_t roff = (uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3));
-        rv[buf][x] = bcast_r ? rb_[j] : (has_r ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)r_lane, (int)(roff * r_pitch + (uint32_t)(j * 128)), 0)) : 0.f);
+        if (RBROWS && bcast_r) rv[buf][x] = e.R[(size_t)sample_of((uint32_t)row_w + roff + 4u * (uint32_t)khalf) * e.ldr + (col_w + j * 32 + lcol)];
+        else rv[buf][x] = bcast_r ? rb_[j] : (has_r ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, (int)r_lane, (int)(roff * r_pitch + (uint32_t)(j * 128)), 0)) : 0.f);
         uv[buf][x] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_u, (int)u_lane, (int)(roff * u_pitch + (uint32_t)(j * 128)), 0));
       }
     };
@@ -101,7 +112,9 @@ __device__ __forceinline__ void epilogue_full(f32x16 (&acc)[TM][TN], const EpiAr
       for (int x = 0; x < G; ++x) {
         const int r = r0 + x;
         const uint32_t roff = (uint32_t)(i * 32 + 8 * (r >> 2) + (r & 3));
-        const float out = fmaxf(acc[i][j][r] + rv[buf][x], floor_v);
+        // (the looked-up broadcast row is scaled here, not where its load is issued: the product would wait for the load)
+        const float res = (RBROWS && bcast_r) ? e.r_scale * rv[buf][x] : rv[buf][x];
+        const float out = fmaxf(acc[i][j][r] + res, floor_v);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(out), rs_c, (int)c_lane, (int)(roff * c_pitch + (uint32_t)(j * 128)), 0);
         float g = (fmaf(uv[buf][x], sc_[j], sh_[j]) > 0.f) ? out : 0.f;
         if (bn_drop.p > 0.f) {

@@ -25,19 +25,24 @@ constexpr int kPad = 32;                 // zero rows on either side of the wind
 // byte offset of 16-byte quad `kq` of row `r` inside a tile image
 __device__ __forceinline__ unsigned img_off(int r, int kq) { return (unsigned)r * 64u + (unsigned)((kq ^ ((r >> 2) & 3)) << 4); }
 
-// SEG: samples per 128-row tile (three-tap launches; 1 otherwise)
+// SEG: samples per 128-row tile (three-tap launches; 1 otherwise).  SEG = 0 is the window for samples of ANY length: a
+// tile's 128 rows start and end anywhere inside samples, so the window also holds the |shift| rows before and after the
+// tile (fetched from the neighbouring tiles' rows: the halo), there are no zero bands, and a tap's contribution to an
+// output row whose shifted time index leaves its sample is dropped where the fragment is used (one select per
+// matrix instruction operand of taps 0 and 2, from four lane masks worked out once).
 template <int BN, int TAPS, bool BNS, int SEG = 1>
 __global__ __launch_bounds__(kThreads, SEG == 4 ? 2 : 3) void gemm_nt_kernel(const GemmBatch batch) {
   const GemmP& p = batch.g[blockIdx.y];
   constexpr int BM = 128, BK = 16;
   constexpr int TM = 2, TN = BN / 64;
   constexpr int A_SLOTS = TAPS == 3 ? 2 : 3, B_SLOTS = 3;
-  constexpr int TS = BM / SEG;                                // rows per sample
-  constexpr int A_ROWS = BM + (TAPS == 3 ? (SEG + 1) * kPad : 0);
+  constexpr bool GEN = TAPS == 3 && SEG == 0;
+  constexpr int TS = GEN ? BM : BM / (SEG > 0 ? SEG : 1);     // rows per sample
+  constexpr int A_ROWS = BM + (TAPS == 3 ? (GEN ? 2 : SEG + 1) * kPad : 0);
   // window position of tile row r: every sample is preceded by a zero band (and the last one followed by one)
-  auto win_row = [](int r) { return TAPS == 3 ? r + kPad * (1 + r / TS) : r; };
+  auto win_row = [](int r) { return TAPS == 3 ? r + kPad * (1 + r / TS) : r; };      // GEN: TS = BM, one band's worth of halo on either side
   constexpr int A_SLOT_BYTES = A_ROWS * 64, B_SLOT_BYTES = BN * 64;
-  constexpr int A_PIECES = 2, B_PIECES = BN / 64;           // float4 per thread per tile
+  constexpr int A_PIECES = GEN ? 3 : 2, B_PIECES = BN / 64; // float4 per thread per tile (GEN: the third is a halo row's)
   __shared__ __align__(16) char smem[A_SLOTS * A_SLOT_BYTES + B_SLOTS * B_SLOT_BYTES];
   char* const As = smem;
   char* const Bs = smem + A_SLOTS * A_SLOT_BYTES;
@@ -67,10 +72,21 @@ __global__ __launch_bounds__(kThreads, SEG == 4 ? 2 : 3) void gemm_nt_kernel(con
   // staging coordinates: piece i of a tile is quad (idx & 3) of row (idx >> 2), idx = tid + 256 i
   unsigned a_goff[A_PIECES], a_loff[A_PIECES], b_goff[B_PIECES], b_loff[B_PIECES];
 #pragma unroll
-  for (int i = 0; i < A_PIECES; ++i) {
+  for (int i = 0; i < 2; ++i) {
     const int idx = tid + i * kThreads, row = idx >> 2, kq = idx & 3;
     a_goff[i] = (unsigned)((m0 + row) * p.lda + kq * 4) * 4u;
     a_loff[i] = img_off(win_row(row), kq);
+  }
+  if (GEN) {
+    // halo: P = |shift| rows above the tile and P below it, one quad per thread (threads 0 .. 8 P - 1).  Rows outside the
+    // matrix are not fetched; the threads left over write zeros to window row 0, which no tap reads while P < kPad
+    const int P = p.shift0 < 0 ? -p.shift0 : p.shift0;
+    const int hr = tid >> 2, kq = tid & 3;
+    int grow = -1, wrow = 0;
+    if (hr < P) { grow = m0 - P + hr; wrow = kPad - P + hr; }
+    else if (hr < 2 * P) { grow = m0 + BM + hr - P; wrow = kPad + BM + hr - P; }
+    a_goff[A_PIECES - 1] = (grow >= 0 && grow < p.M) ? (unsigned)(grow * p.lda + kq * 4) * 4u : kOob;
+    a_loff[A_PIECES - 1] = img_off(wrow, kq);
   }
 #pragma unroll
   for (int i = 0; i < B_PIECES; ++i) {
@@ -82,7 +98,7 @@ __global__ __launch_bounds__(kThreads, SEG == 4 ? 2 : 3) void gemm_nt_kernel(con
   auto load_a = [&](int chunk) {      // activation rows of reduction chunk `chunk` (zeros past the end)
     const bool ok = chunk < n_chunks;
 #pragma unroll
-    for (int i = 0; i < A_PIECES; ++i) ra[i] = buf_load(rsrc_a, ok ? a_goff[i] : kOob, chunk * (BK * 4));
+    for (int i = 0; i < A_PIECES; ++i) ra[i] = buf_load(rsrc_a, ok ? a_goff[i] : kOob, chunk * (BK * 4));      // (an out-of-range offset stays out of range)
   };
   auto load_b = [&](int tap, int chunk) {
     const bool ok = chunk < n_chunks;
@@ -100,7 +116,7 @@ __global__ __launch_bounds__(kThreads, SEG == 4 ? 2 : 3) void gemm_nt_kernel(con
 
   // fragment addresses: this lane's row of sub-tile 0 (sub-tile 1 is 32 rows further - 64 when a zero band lies between
   // them - with the same swizzle), one address per 8-deep half q of a tile and, for the window, per tap
-  constexpr int A_SUB = (TAPS == 3 && SEG == 4) ? 4096 : 2048;
+  constexpr int A_SUB = (TAPS == 3 && SEG == 4) ? 4096 : 2048;      // (GEN: no band between the sub-tiles)
   unsigned a_rd[TAPS][2], b_rd[2];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) {
@@ -112,7 +128,20 @@ __global__ __launch_bounds__(kThreads, SEG == 4 ? 2 : 3) void gemm_nt_kernel(con
 #pragma unroll
   for (int q = 0; q < 2; ++q) b_rd[q] = img_off(wn * (BN / 2) + lm, 2 * q + h);
 
-  if (TAPS == 3) {
+  // GEN: whether tap 0 / tap 2 of this lane's row of sub-tile i stays inside the row's sample
+  bool tap_ok[2][TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { tap_ok[0][i] = true; tap_ok[1][i] = true; }
+  if (GEN) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int tpos = (m0 + wm * 64 + i * 32 + lm) % p.T;
+      tap_ok[0][i] = (unsigned)(tpos + p.shift0) < (unsigned)p.T;
+      tap_ok[1][i] = (unsigned)(tpos + p.shift0 + 2 * p.shift_step) < (unsigned)p.T;
+    }
+  }
+
+  if (TAPS == 3 && !GEN) {
     // the zero bands of both window slots (band b: rows [b (TS + kPad), b (TS + kPad) + kPad)), never written again
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int kBandQuads = (SEG + 1) * kPad * 4;
@@ -147,12 +176,14 @@ __global__ __launch_bounds__(kThreads, SEG == 4 ? 2 : 3) void gemm_nt_kernel(con
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb[half][j] = *reinterpret_cast<const float4*>(Bs + b_slot * B_SLOT_BYTES + b_rd[q] + j * 2048);
   };
-  auto mfma_group = [&](int half, int t) {
+  auto mfma_group = [&](int half, int t, auto tap_c) {
+    constexpr int TAP = decltype(tap_c)::value;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const float av = t == 0 ? fa[half][i].x : t == 1 ? fa[half][i].y : t == 2 ? fa[half][i].z : fa[half][i].w;
+        float av = t == 0 ? fa[half][i].x : t == 1 ? fa[half][i].y : t == 2 ? fa[half][i].z : fa[half][i].w;
+        if (GEN && TAP != 1) av = tap_ok[TAP / 2][i] ? av : 0.f;
         const float bv = t == 0 ? fb[half][j].x : t == 1 ? fb[half][j].y : t == 2 ? fb[half][j].z : fb[half][j].w;
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
       }
@@ -173,26 +204,26 @@ __global__ __launch_bounds__(kThreads, SEG == 4 ? 2 : 3) void gemm_nt_kernel(con
     const bool more = it + 1 < n_iter;
     read_frags(1, ASLOT, BSLOT, TAP, 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_group(0, 0);
+    mfma_group(0, 0, tap_c);
     // tile it+1's weights -> ring, tile it+2's weights -> registers
     store_b(NB);
     if (TAPS == 3) load_b((TAP + 2) % 3, chunk + (TAP + 2) / 3);
     else load_b(0, chunk + 2);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_group(0, 1);
+    mfma_group(0, 1, tap_c);
     if (TAPS == 1) { store_a(NA); load_a(chunk + 2); }
     else if (TAP == 2) store_a(NA);
     else if (TAP == 1) load_a(chunk + 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_group(0, 2);
-    mfma_group(0, 3);
+    mfma_group(0, 2, tap_c);
+    mfma_group(0, 3, tap_c);
     __syncthreads();
     if (more) read_frags(0, NA, NB, NTAP, 0);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_group(1, 0);
-    mfma_group(1, 1);
-    mfma_group(1, 2);
-    mfma_group(1, 3);
+    mfma_group(1, 0, tap_c);
+    mfma_group(1, 1, tap_c);
+    mfma_group(1, 2, tap_c);
+    mfma_group(1, 3, tap_c);
     __builtin_amdgcn_sched_barrier(0);
     if (NEXT_CHUNK) ++chunk;
   };
@@ -220,7 +251,7 @@ __global__ __launch_bounds__(kThreads, SEG == 4 ? 2 : 3) void gemm_nt_kernel(con
 
   const EpiArgs e = make_epi_args(p);
   const DropoutP bn_drop = BNS ? dropout_resolve(p.bn_drop) : DropoutP{0.f, 0, nullptr};
-  epilogue_full<BM, BN, false, BNS>(acc, e, e.C, bn_drop, m0, n0, tile_m, wave, lane);
+  epilogue_full<BM, BN, false, BNS, GEN>(acc, e, e.C, bn_drop, m0, n0, tile_m, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -431,10 +462,12 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 template <int BN, int TAPS, int SEG = 1>
 void launch_nt(const GemmBatch& b, dim3 grid, hipStream_t stream) {
-  if (ocean_split_bf16()) {
-    if (b.g[0].bn_u != nullptr) hipLaunchKernelGGL((gemm_nt_bf3_kernel<BN, TAPS, true, SEG>), grid, dim3(kThreads), 0, stream, b);
-    else hipLaunchKernelGGL((gemm_nt_bf3_kernel<BN, TAPS, false, SEG>), grid, dim3(kThreads), 0, stream, b);
-    return;
+  if constexpr (SEG != 0) {            // the split-operand kernel has no general window (ocean_gemm_nt_applies)
+    if (ocean_split_bf16()) {
+      if (b.g[0].bn_u != nullptr) hipLaunchKernelGGL((gemm_nt_bf3_kernel<BN, TAPS, true, SEG>), grid, dim3(kThreads), 0, stream, b);
+      else hipLaunchKernelGGL((gemm_nt_bf3_kernel<BN, TAPS, false, SEG>), grid, dim3(kThreads), 0, stream, b);
+      return;
+    }
   }
   if (b.g[0].bn_u != nullptr) hipLaunchKernelGGL((gemm_nt_kernel<BN, TAPS, true, SEG>), grid, dim3(kThreads), 0, stream, b);
   else hipLaunchKernelGGL((gemm_nt_kernel<BN, TAPS, false, SEG>), grid, dim3(kThreads), 0, stream, b);
@@ -445,13 +478,15 @@ void launch_nt_taps(const GemmBatch& b, dim3 grid, hipStream_t stream) {
   if (p.taps != 3) launch_nt<BN, 1>(b, grid, stream);
   else if (p.T == 128) launch_nt<BN, 3, 1>(b, grid, stream);
   else if (p.T == 64) launch_nt<BN, 3, 2>(b, grid, stream);
-  else launch_nt<BN, 3, 4>(b, grid, stream);
+  else if (p.T == 32) launch_nt<BN, 3, 4>(b, grid, stream);
+  else launch_nt<BN, 3, 0>(b, grid, stream);
 }
 
 }  // namespace
 
 // One problem, both operands k-contiguous, every tile full, enough tiles to fill the chip; a three-tap problem must have
-// whole samples in a row tile (T = 128, 64 or 32) and symmetric shifts within the zero bands.
+// symmetric shifts no longer than a zero band (samples of 128, 64 or 32 rows sit whole in a row tile; any other length
+// takes the window with halo rows and per-row tap masks).
 bool ocean_gemm_nt_applies(const GemmBatch& b) {
   static const bool off = getenv("OCEAN_GEMM_NO_NT") != nullptr;          // measurement switch
   if (off || b.n != 1) return false;
@@ -464,10 +499,18 @@ bool ocean_gemm_nt_applies(const GemmBatch& b) {
   if (!al16(p.A) || !al16(p.B) || p.lda % 4 != 0 || p.ldb % 4 != 0 || p.tap_stride_b % 4 != 0) return false;
   if ((double)p.M * p.lda >= 5.0e8 || (double)p.N * p.ldb + (double)(p.taps - 1) * (double)p.tap_stride_b >= 5.0e8) return false;
   if (p.taps == 3) {
-    if ((p.T != 128 && p.T != 64 && p.T != 32) || p.shift_step != -p.shift0 || p.shift0 > kPad || p.shift0 < -kPad) return false;
+    if (p.T < 1 || p.shift_step != -p.shift0 || p.shift0 > kPad || p.shift0 < -kPad) return false;
+    const bool whole = p.T == 128 || p.T == 64 || p.T == 32;
+    if (!whole && (ocean_split_bf16() || p.M % p.T != 0)) return false;       // the general window exists in fp32 only
   }
   if (p.drop.p > 0.f || p.relu_mask != nullptr || p.a_colsum != nullptr) return false;
-  if (p.r_bcast_T > 0 && (p.bn_u == nullptr || p.R == nullptr || p.r_bcast_T % 128 != 0)) return false;
+  if (p.r_bcast_T > 0) {
+    if (p.bn_u == nullptr || p.R == nullptr) return false;
+    // a broadcast residual row is block-uniform when tiles lie inside samples; the general window looks it up per row
+    // (rows below 2^24: the epilogue divides in fp32)
+    const bool general = p.taps == 3 && p.T != 128 && p.T != 64 && p.T != 32;
+    if (p.r_bcast_T % 128 != 0 && !(general && p.r_bcast_T == p.T && p.M < (1 << 24))) return false;
+  }
   if (p.bn_u != nullptr && (p.bias != nullptr || (double)p.M * (double)p.N >= 4294967296.0)) return false;
   return true;
 }
@@ -479,7 +522,8 @@ int ocean_launch_gemm_nt(const GemmBatch& b, hipStream_t stream) {
   void* tok = nullptr;
   if (ocean_prof_on()) {
     char name[96];
-    snprintf(name, sizeof(name), "gemm_nt%s_kernel<%d,%d%s>", ocean_split_bf16() ? "_bf3" : "", bn, p.taps, p.bn_u != nullptr ? ",bn-sums" : "");
+    const bool halo = p.taps == 3 && p.T != 128 && p.T != 64 && p.T != 32;
+    snprintf(name, sizeof(name), "gemm_nt%s_kernel<%d,%d%s%s>", ocean_split_bf16() ? "_bf3" : "", bn, p.taps, p.bn_u != nullptr ? ",bn-sums" : "", halo ? ",halo" : "");
     double bytes = 4.0 * ((double)p.M * p.K + (double)p.N * p.K * p.taps + (double)p.M * p.N);
     if (p.R != nullptr) bytes += 4.0 * (p.r_bcast_T > 0 ? (double)p.M / p.r_bcast_T : (double)p.M) * p.N;
     if (p.bn_u != nullptr) bytes += 4.0 * (double)p.M * p.N;

