@@ -166,6 +166,46 @@ def all_gather_rows(x: torch.Tensor, group_or_transport=None) -> torch.Tensor:
     return _AllGatherRows.apply(x, t)
 
 
+class _AllGatherRowsRagged(torch.autograd.Function):
+    """counts[r] rows on rank r -> [sum(counts), ...] on every rank, in rank order; backward: every rank receives the sum
+    over ranks of the gradients of its own rows.  The collectives move max(counts) row slots per rank (the tail of a
+    shorter rank's slots is zero and is dropped on arrival).  A rank whose count is 0 may pass any number of rows (its
+    stand-in batch): none of them is sent, and their gradient is zero."""
+
+    @staticmethod
+    def forward(ctx, x, transport, counts):
+        counts = [int(c) for c in counts]
+        n, slots = counts[transport.rank], max(max(counts), 1)
+        if x.shape[0] < n:
+            raise ValueError(f"rank {transport.rank} holds {x.shape[0]} rows, the step's table says {n}")
+        send = torch.zeros(slots, *x.shape[1:], device=x.device, dtype=x.dtype)
+        send[:n] = x[:n]
+        out = torch.empty(transport.world * slots, *x.shape[1:], device=x.device, dtype=x.dtype)
+        transport.all_gather(out, send)
+        ctx.transport, ctx.counts, ctx.slots, ctx.local_rows = transport, counts, slots, x.shape[0]
+        return torch.cat([out[r * slots: r * slots + c] for r, c in enumerate(counts)], dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        t, counts, slots = ctx.transport, ctx.counts, ctx.slots
+        padded = torch.zeros(t.world * slots, *g.shape[1:], device=g.device, dtype=g.dtype)
+        at = 0
+        for r, c in enumerate(counts):
+            padded[r * slots: r * slots + c] = g[at: at + c]
+            at += c
+        mine = torch.empty(slots, *g.shape[1:], device=g.device, dtype=g.dtype)
+        t.reduce_scatter(mine, padded)
+        gx = torch.zeros(ctx.local_rows, *g.shape[1:], device=g.device, dtype=g.dtype)
+        n = counts[t.rank]
+        gx[:n] = mine[:n]
+        return gx, None, None
+
+
+def all_gather_rows_ragged(x: torch.Tensor, counts, group_or_transport=None) -> torch.Tensor:
+    t = group_or_transport if isinstance(group_or_transport, Transport) else Transport(group_or_transport)
+    return _AllGatherRowsRagged.apply(x, t, counts)
+
+
 class GradBucket:
     """Flat fp32 bucket over a list of gradient tensors: pack, one all-reduce, average, unpack.  Used for gradients that
     do not live in an arena (a model driven without OnlineLearner / Trainer); the bucket is reused across steps."""
@@ -246,8 +286,8 @@ class DataParallel:
         fm = getattr(model, "fusion_module", None)
         if fm is not None:
             cm = fm.contrastive_module
-            cm.gather_positives = lambda z: z if self._rows_all is not None else all_gather_rows(z, self.transport)
-            cm.rank_row_offset = lambda local_rows: 0 if self._rows_all is not None else self.rank * local_rows
+            cm.gather_positives = self._gather_positives
+            cm.rank_row_offset = self._row_offset
             cm.gather_bank_rows = self._gather_bank_rows
         if learner is not None:
             learner.grad_sync = self.sync_grads
@@ -260,8 +300,9 @@ class DataParallel:
     def set_step_rows(self, rows_per_rank: Optional[List[int]]) -> None:
         """Tell the wiring how many sample rows every rank holds in the coming step (sharded streams: the ranks'
         batches differ in size; a rank with none runs a one-row stand-in batch that counts as 0 rows).  None: equal
-        batches on every rank (the default).  With unequal batches the in-batch InfoNCE negatives stay rank-local
-        (a gather needs equal row counts); memory-bank rows are gathered padded and written by their true counts."""
+        batches on every rank (the default).  With unequal batches the gathers of projections (in-batch InfoNCE
+        negatives, memory-bank rows) move max-count row slots per rank and keep each rank's true rows, so the negatives
+        of every anchor are the rows of the whole step's batch, as in a single process (graph_fusion.py:144-157)."""
         if rows_per_rank is None:
             self._rows_local = self._rows_global = self._rows_all = None
         else:
@@ -290,6 +331,20 @@ class DataParallel:
             t.zero_()
         work = self.transport.all_reduce(t, "sum", async_op=True)
         return work if work is not None else _Done()
+
+    # ------------------------------------------------------------------ in-batch negatives
+    def _gather_positives(self, z: torch.Tensor) -> torch.Tensor:
+        """[B_loc, W] projections of this rank -> the rows of all ranks in rank order, keeping autograd."""
+        if self._rows_all is None:
+            return all_gather_rows(z, self.transport)
+        return all_gather_rows_ragged(z, self._rows_all, self.transport)
+
+    def _row_offset(self, local_rows: int) -> int:
+        """Where this rank's rows start in the gathered batch: the label of anchor i is offset + i.  (A stand-in
+        batch has no rows there; its one anchor points at row 0 and its loss carries weight 0.)"""
+        if self._rows_all is None:
+            return self.rank * local_rows
+        return sum(self._rows_all[:self.rank]) if self._rows_all[self.rank] > 0 else 0
 
     # ------------------------------------------------------------------ memory bank
     def _gather_bank_rows(self, rows: torch.Tensor) -> torch.Tensor:

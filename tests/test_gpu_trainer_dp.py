@@ -297,7 +297,7 @@ def _shard_gpu_worker(rank, world, port, fix, out):
         zero_dropout(m)
         m.load_state_dict({k: v.clone() for k, v in fix["sd"].items()})
         m = m.cuda()
-        m.contrastive_negatives = "bank"
+        m.contrastive_negatives = fix["negatives"]
         learner = OnlineLearner(m, cfg)
         dp = DataParallel(m, learner, transport=HostStagedTransport())
         sg = ServiceGraph(fix["adj"], fix["nf"])
@@ -319,14 +319,17 @@ def _shard_gpu_worker(rank, world, port, fix, out):
         dist.destroy_process_group()
 
 
-def test_sharded_streams_two_ranks_uneven_arrivals_match_the_union_batches():
+@pytest.mark.parametrize("negatives", ["bank", "in_batch"])
+def test_sharded_streams_two_ranks_uneven_arrivals_match_the_union_batches(negatives):
     """Two ranks, uneven arrivals on their streams (5 and 3 samples, chunks of 4): step 0 trains on rank 0's 4 rows and
-    rank 1's 3, step 1 on rank 0's last row while rank 1 takes part with a weightless stand-in.  With memory-bank
-    negatives every coupling is exact (BatchNorm statistics over the real rows of both ranks, losses and gradients
-    weighted by row counts, the ranks' projections written into the ring in rank order), so both ranks must end with
+    rank 1's 3, step 1 on rank 0's last row while rank 1 takes part with a weightless stand-in.  Every coupling is exact
+    (BatchNorm statistics over the real rows of both ranks, losses and gradients weighted by row counts; with
+    memory-bank negatives the ranks' projections written into the ring in rank order, with in-batch negatives every
+    anchor scored against the 7 (then 1) rows of both ranks, gathered by their true counts), so both ranks must end with
     the same state as ONE process that takes two update steps on the union batches [0-3, 5-7] and [4]."""
     import torch.multiprocessing as mp
     fix = _fixture()
+    fix["negatives"] = negatives
     ctx = mp.get_context("spawn")
     out = ctx.Manager().dict()
     mp.spawn(_shard_gpu_worker, args=(2, _free_port(), fix, out), nprocs=2, join=True)
@@ -344,7 +347,7 @@ def test_sharded_streams_two_ranks_uneven_arrivals_match_the_union_batches():
     for rows in ([0, 1, 2, 3, 5, 6, 7], [4]):
         for k in tk:
             rsd[k].grad = None
-        ro = R.model_forward(rsd, fix["metrics"][rows], fix["adj"], fix["nf"], fix["logs"][rows], training=True, negatives="bank",
+        ro = R.model_forward(rsd, fix["metrics"][rows], fix["adj"], fix["nf"], fix["logs"][rows], training=True, negatives=negatives,
                              dilations=(1, 2), gnn_heads=2, log_dim=24)
         rl = R.compute_loss(ro, fix["labels"][rows])
         rl["total_loss"].backward()

@@ -74,6 +74,54 @@ def test_two_rank_equals_full_batch():
     assert dict(out) == {0: (True, True, True), 1: (True, True, True)}
 
 
+def _ragged_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ocean.parallel import GradBucket, Transport, all_gather_rows_ragged
+        x, y, wa0, wp0, loss_full, ga_full, gp_full = _full_batch_reference()
+        results = []
+        # 5 + 3 rows; then 8 + 0, rank 1 taking part with a one-row stand-in that must count for nothing
+        for counts in ([5, 3], [8, 0]):
+            lo = sum(counts[:rank])
+            n = counts[rank]
+            xs, ys = (x[lo:lo + n], y[lo:lo + n]) if n > 0 else (x[:1] * 3.0, y[:1] * -2.0)
+            wa, wp = wa0.clone().requires_grad_(True), wp0.clone().requires_grad_(True)
+            a = F.normalize(xs @ wa.t(), dim=1)
+            p_all = F.normalize(all_gather_rows_ragged(ys @ wp.t(), counts), dim=1)
+            assert p_all.shape[0] == sum(counts)
+            logits = a @ p_all.t() / 0.1
+            labels = torch.arange(xs.shape[0]) + (lo if n > 0 else 0)
+            weight = world * n / float(sum(counts))                       # DataParallel.loss_weight
+            loss = F.cross_entropy(logits, labels) * weight
+            loss.backward()
+            GradBucket().all_reduce_mean([wa.grad, wp.grad])
+            lt = loss.detach().clone()
+            dist.all_reduce(lt)
+            results.append(bool(torch.allclose(lt / world, loss_full, atol=1e-5) and torch.allclose(wa.grad, ga_full, atol=1e-5)
+                                and torch.allclose(wp.grad, gp_full, atol=1e-5)))
+        # a table that promises more rows than the rank holds is refused before any collective
+        try:
+            all_gather_rows_ragged(torch.zeros(1, 3), [2, 2] if rank == 0 else [2, 2], Transport(None))
+            results.append(False)
+        except ValueError:
+            results.append(True)
+        out[rank] = tuple(results)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ragged_gather_of_in_batch_negatives_equals_the_union_batch():
+    """Unequal row counts per rank (sharded streams): anchors are scored against the rows of ALL ranks, gathered by their
+    true counts; with the row-count loss weights the rank-averaged gradient is the union batch's (graph_fusion.py:144-157
+    evaluated by one process on all rows)."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ragged_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: (True, True, True), 1: (True, True, True)}
+
+
 def _wire_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
