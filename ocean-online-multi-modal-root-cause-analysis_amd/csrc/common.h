@@ -159,6 +159,13 @@ int ocean_launch_gemm_nt(const GemmBatch& b, hipStream_t stream);
 
 // the kernel for long row reductions into full 128x128 tiles (gemm_tn.hip), likewise
 bool ocean_gemm_tn_applies(const GemmBatch& b);
+// A row reduction (weight gradient) whose output is a dozen 128x128 tile-taps or fewer over fewer than 65536 rows is
+// bound by the atomic adds of its row slices, and 64x64 tiles need a quarter of the slices to fill the chip: measured at
+// 16384 rows, 128x128x3 taps 25 against 34 us, 256x256x3 68 against 78, 256x128 19 against 27, 512x256 46 against 58
+// (at 32768 rows 36 / 47, 120 / 124, 28 / 38, 85 / 93).  Such problems take the ring kernel's 64x64 tiles.
+inline bool ocean_wgrad_small_tiles(const GemmP& p) {
+  return p.a_kmajor && p.K < 65536 && (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.taps <= 12;
+}
 int ocean_launch_gemm_tn(const GemmBatch& b, hipStream_t stream);
 
 // optional kernel timing (prof.hip); token is null while profiling is off

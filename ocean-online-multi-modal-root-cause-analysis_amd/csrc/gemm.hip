@@ -556,7 +556,7 @@ void pick_tile(const GemmBatch& b, bool akm, int* bm_out, int* bn_out, int* k_ou
   }
   const bool big_m = tiles128 >= 256;
   int bm, bn;
-  if (akm && M >= 128 && N >= 128 && K >= wg_big_k()) { bm = 128; bn = 128; }   // long row reductions fill the chip through split-K
+  if (akm && M >= 128 && N >= 128 && K >= wg_big_k() && !(b.n == 1 && ocean_wgrad_small_tiles(b.g[0]))) { bm = 128; bn = 128; }   // long row reductions fill the chip through split-K
   else if (!akm && N > 64 && big_m) { bm = 128; bn = 128; }
   else if (!akm && N <= 64 && (long)ceil_div(M, 128) * b.n >= 256) { bm = 128; bn = 64; }
   else { bm = 64; bn = 64; }

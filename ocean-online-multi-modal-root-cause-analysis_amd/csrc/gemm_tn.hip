@@ -352,6 +352,7 @@ bool ocean_gemm_tn_applies(const GemmBatch& b) {
   const GemmP& p = b.g[0];
   if (!p.a_kmajor || !p.b_kn || p.a_colsum != nullptr || p.bias != nullptr) return false;
   if (p.M % BM != 0 || p.N % BN != 0 || p.K % BK != 0 || p.K < 8192) return false;
+  if (!ocean_split_bf16() && ocean_wgrad_small_tiles(p)) return false;      // (the split-operand form exists in this kernel only)
   if (p.T > 0 && p.T < 8) return false;                  // a row's time index is wrapped at most twice per 16-row tile
   if (p.taps > 1 && p.T <= 0) return false;
   if (!al16(p.A) || !al16(p.B) || p.lda % 4 != 0 || p.ldb % 4 != 0) return false;

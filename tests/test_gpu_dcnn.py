@@ -118,11 +118,12 @@ def test_against_oracle_random(B, T_, ch, dil, k):
             close(v, ref_sd[name], 1e-5)
 
 
-@pytest.mark.parametrize("B,T_,dil", [(352, 100, [3, 8]), (344, 96, [2, 5]), (704, 50, [1, 32]), (1664, 20, [4, 2]), (3328, 10, [1, 2])])
+@pytest.mark.parametrize("B,T_,dil", [(672, 100, [3, 8]), (344, 96, [2, 5]), (704, 50, [1, 32]), (1664, 20, [4, 2]), (3328, 10, [1, 2])])
 def test_any_sequence_length_takes_the_window_and_lean_kernels(B, T_, dil):
     """Samples that do not tile 128 rows (the reference's default T = 100, its demo's 20, its README's 10): the forward
     convolutions and their data gradients still run in the LDS-window kernel (halo rows + per-row tap masks) and the
-    128-channel weight gradient in the lean row-reduction kernel; results against the oracle under the large-row rule."""
+    128-channel weight gradient - from 65 536 rows on, below that 64x64 tiles serve it better - in the lean row-reduction
+    kernel; results against the oracle under the large-row rule."""
     from ocean import _hip
     from ocean.models.components import DilatedCNN
     from parity_rules import gradient_gates, to_double
@@ -152,7 +153,7 @@ def test_any_sequence_length_takes_the_window_and_lean_kernels(B, T_, dil):
     halo = {name: n for name, n in ran.items() if name.startswith("gemm_nt_kernel<") and name.endswith(",halo>")}
     assert sum(halo.values()) == 4, ran
     assert sum(n for name, n in halo.items() if "bn-sums" in name) == 1, ran
-    assert ran.get("gemm_tn_kernel", 0) == 1, ran
+    assert ran.get("gemm_tn_kernel", 0) == (1 if B * T_ >= 65536 else 0), ran
     close(y, yr, 1e-4)
     sd64 = R.require_grad(to_double(sd))
     x64 = x.double().requires_grad_(True)

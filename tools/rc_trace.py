@@ -45,13 +45,6 @@ def show(tag):
     print(f"== {tag}: {n} operations, {(rows[-1][1] - rows[0][1]) / 100.0:.1f} us; whole kernel {wall:.1f} us = {cyc} shader cycles -> {cyc / max(wall, 1e-9) / 1e3:.2f} GHz")
     for (k, c), (_, c2) in zip(rows[:-1], rows[1:]):
         print(f"   {KINDS[k // 1000]:12s} width {k % 1000:4d}  {(c2 - c) / 100.0:6.2f} us")
-    for i in range(n):
-        k = t[2 * i]
-        if k // 1000 == 0 and k % 1000 > 0:
-            tr = t[64 + 8 * i: 64 + 8 * i + 7]
-            if tr[0]:
-                print(f"   LIN op {i} wave 0 item 0: issue loads {(tr[1]-tr[0])/100:.2f}  first chunk waited+issued {(tr[2]-tr[1])/100:.2f}  rest {(tr[3]-tr[2])/100:.2f}  "
-                      f"mfma drain {(tr[4]-tr[3])/100:.2f}  epilogue {(tr[6]-tr[4])/100:.2f} us; op start->item start {(tr[0]-t[2*i+1])/100:.2f}")
     buf.zero_()
 
 
