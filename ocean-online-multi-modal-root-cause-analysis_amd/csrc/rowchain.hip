@@ -75,9 +75,16 @@ __device__ __forceinline__ void lds_barrier() {
 
 // Operand k as (pointer, leading dimension) such that element (row r of the operation's matrix, column c) is
 // ptr[r * ld + c]: the LDS slot (rebased by the tile's first row) when the host planned one, else memory.
+// The rebased slot address lies below the slot (by the rows of the blocks in front of this one) until a row index is
+// added back, so it is worked out on the 64-bit flat address: as LDS pointer arithmetic it wraps at 32 bits, and the
+// carry of the later 64-bit add then lands in the aperture half of the flat address (a memory fault in every block
+// but the first).
 struct Opnd { float* ptr; int ld; bool lds; };
 __device__ __forceinline__ Opnd opnd(const RcOp& op, const int k, float* lds, const int rows0) {
-  if (op.loff[k] >= 0) return Opnd{lds + 4 * (int)op.loff[k] - (long)rows0 * op.lld[k], op.lld[k], true};
+  if (op.loff[k] >= 0) {
+    const uintptr_t slot = reinterpret_cast<uintptr_t>(lds) + 16ull * (uintptr_t)op.loff[k];
+    return Opnd{reinterpret_cast<float*>(slot - 4ull * (uintptr_t)((long)rows0 * op.lld[k])), op.lld[k], true};
+  }
   return Opnd{mpf(op.p[k]), op.ld[k], false};
 }
 // one row of an LDS-resident output to its place in memory (by the wave that has just written it)

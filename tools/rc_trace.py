@@ -34,17 +34,22 @@ m.train()
 def show(tag):
     torch.cuda.synchronize()
     t = buf.cpu().tolist()
-    rows = []
+    rows, n = [], 0          # (kind, stamp, operations sharing the stamp: the members of a group of independent layers)
     for i in range(0, 60):
         k, c = t[2 * i], t[2 * i + 1]
-        rows.append((k, c))
+        n = i
         if k == -1:
+            rows.append((k, c, 0))
             break
-    n = len(rows) - 1
+        if c == 0 and rows:      # a group member: it runs inside its group head's pass
+            rows[-1] = (rows[-1][0], rows[-1][1], rows[-1][2] + 1)
+        else:
+            rows.append((k, c, 1))
     cyc, wall = t[2 * n + 3] - t[2 * n + 2], (t[2 * n + 1] - t[2 * n + 4]) / 100.0
     print(f"== {tag}: {n} operations, {(rows[-1][1] - rows[0][1]) / 100.0:.1f} us; whole kernel {wall:.1f} us = {cyc} shader cycles -> {cyc / max(wall, 1e-9) / 1e3:.2f} GHz")
-    for (k, c), (_, c2) in zip(rows[:-1], rows[1:]):
-        print(f"   {KINDS[k // 1000]:12s} width {k % 1000:4d}  {(c2 - c) / 100.0:6.2f} us")
+    for (k, c, members), (_, c2, _m) in zip(rows[:-1], rows[1:]):
+        group = f"  (group of {members} independent layers)" if members > 1 else ""
+        print(f"   {KINDS[k // 1000]:12s} width {k % 1000:4d}  {(c2 - c) / 100.0:6.2f} us{group}")
     buf.zero_()
 
 
