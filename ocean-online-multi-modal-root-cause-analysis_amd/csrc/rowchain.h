@@ -16,8 +16,9 @@
 //    every operation, activations handed from operation to operation through LDS slots the host plans while recording
 //    (and written through to their workspace buffers for the backward pass).  It passes every test, and it is not the
 //    default because it is not faster: a block is one compute unit working through ~20 dependent steps, each of which
-//    waits 1-2.5 us for its weights (tools/rc_trace.py prints the per-operation timeline), so a chain costs as much as
-//    the launches it replaces (attention forward 100 us against 85 us at batch 128; update step 2.8 against 2.3 ms).
+//    waits for its weights from L2 - all of the stage's ~8 MB pass through that one unit's load path - (tools/rc_trace.py
+//    prints the per-operation timeline), so a chain costs more than
+//    the launches it replaces (attention forward 155 us against 85 us at batch 128; update step 2.8 against 2.2 ms).
 //    What would change that is streaming the weights of upcoming layers into LDS ahead of the layers that use them
 //    (they do not depend on the activations) with dedicated producer waves; not built.
 //
