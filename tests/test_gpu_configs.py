@@ -286,15 +286,15 @@ def _oracle_step_fp32_and_fp64(sd, metrics, adj, nf, logs, labels):
     return rprobs, rl, rsd, rsd64
 
 
-def test_c2_full_size_matches_oracle():
-    """The single-GPU online-training configuration at its stated size: 64 services, batch 256, 64 timesteps, in-batch
-    InfoNCE, dropout 0.  Probabilities 1e-4 relative, identical top-k, the three losses and the gradient norm 1e-3, every
-    gradient tensor by the large-row rule (16 384 rows), the dead query / key projections exact zeros."""
+def _full_size_step_against_oracle(N, B, T, degree):
+    """One whole-model update step (in-batch InfoNCE, dropout 0) against the oracle: probabilities 1e-4 relative, identical
+    top-k, the three losses and the gradient norm 1e-3, every gradient tensor by the large-row rule, the dead query / key
+    projections exact zeros.  Returns the names of the GEMM kernels the step launched."""
     import ocean
+    from ocean import _hip
     from ocean.data import ServiceGraph
     from ocean.optim import FusedAdam
     from parity_rules import gradient_gates
-    N, B, T = 64, 256, 64
     cfg = ocean.default_config()
     cfg.model.num_services = N
     m = ocean.OCEANModel(cfg)
@@ -304,13 +304,19 @@ def test_c2_full_size_matches_oracle():
     m = m.cuda().train()
     m.contrastive_negatives = "in_batch"
     gen = torch.Generator().manual_seed(12)
-    adj, nf = synth.random_digraph(N, 4.0, 11), torch.randn(N, 12, generator=gen)
+    adj, nf = synth.random_digraph(N, degree, 11), torch.randn(N, 12, generator=gen)
     metrics, logs = torch.randn(B, T, 12, generator=gen), torch.randn(B, 768, generator=gen)
     labels = torch.zeros(B, N)
     labels[torch.arange(B), torch.randint(0, N, (B,), generator=gen)] = 1.0
-    out = m(metrics, ServiceGraph(adj, nf), logs)
-    losses = m.compute_loss(out, labels.cuda())
-    losses["total_loss"].backward()
+    _hip.profile_enable(True)
+    try:
+        out = m(metrics, ServiceGraph(adj, nf), logs)
+        losses = m.compute_loss(out, labels.cuda())
+        losses["total_loss"].backward()
+        torch.cuda.synchronize()
+        ran = {row["kernel"] for row in _hip.profile_summary()}
+    finally:
+        _hip.profile_enable(False)
     opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=1e-5)
     opt.step(max_norm=1.0, write_clipped=False)
     gnorm = float(opt.grad_norm())
@@ -329,6 +335,23 @@ def test_c2_full_size_matches_oracle():
         assert float(got[k].abs().max()) == 0.0, k
     assert set(tk) <= set(got)
     gradient_gates([(k, got[k], rsd[k].grad, rsd64[k].grad) for k in tk])
+    return ran
+
+
+def test_c2_full_size_matches_oracle():
+    """The single-GPU online-training configuration at its stated size: 64 services, batch 256, 64 timesteps (16 384
+    rows)."""
+    _full_size_step_against_oracle(64, 256, 64, 4.0)
+
+
+def test_default_sequence_length_whole_model_matches_oracle():
+    """The reference's default window of 100 timesteps (configs/default_config.py:62) at a batch that puts the temporal
+    encoder on the large-tile kernels (352 x 100 = 35 200 rows = 275 row tiles that straddle samples): the window kernel's
+    halo variant and the lean weight-gradient kernel must have run, and the whole step must match the oracle."""
+    ran = _full_size_step_against_oracle(64, 352, 100, 4.0)
+    assert any(k.startswith("gemm_nt_kernel<") and k.endswith(",halo>") for k in ran), ran
+    assert any("bn-sums,halo" in k for k in ran), ran
+    assert "gemm_tn_kernel" in ran, ran
 
 
 # ---------------------------------------------------------------- the headline shape, once, at full size
